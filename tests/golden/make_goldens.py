@@ -1,0 +1,391 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures that pin the oracle (and, through it, the HIP engine).
+
+Runs ONLY in the build container, where the reference is mounted read-only at /root/reference:
+it imports the reference's own `ODENet`, `odeint`, `odeint_adjoint` and (by AST extraction, the
+module itself is a script) `training_step`, runs them on small seeded inputs and stores
+inputs + outputs as .npz files next to this script.  The fixtures are data only; no reference
+source travels.  Re-run with:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py
+
+Goldens:
+  G1 rhs            ODENet.forward / prior_only_forward                    (odenet.py:85-98)
+  G2 rhs_vjp        torch.autograd.grad(f, (y, *params), cot)              (adjoint.py:116-119)
+  G3 fixed          odeint / odeint_adjoint with euler, midpoint, rk4      (fixed_grid.py, solvers.py)
+  G4 dopri5         odeint / odeint_adjoint, per-sample, batched, fp64 t, decreasing t
+  G5 training_step  one full reference training_step + Adam update         (train_insilico.py:124-140)
+  G6 controller     _select_initial_step pieces, error ratio, step size, interpolation, norms
+  G7 realdata       first pairs of shipped yeast / breast CSVs with a seeded H=8 net
+"""
+import ast
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+REF = "/root/reference/ode_net/code"
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from odenet import ODENet  # noqa: E402  (reference)
+from torchdiffeq import odeint, odeint_adjoint  # noqa: E402  (reference, vendored 0.1.1)
+from torchdiffeq._impl import misc as ref_misc  # noqa: E402
+from torchdiffeq._impl import interp as ref_interp  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)
+
+
+def make_net(N, H, seed, dense_std=None, neg_g_frac=0.0):
+    """Reference ODENet; `dense_std` overwrites the 95%-sparse init with a trained-like dense one
+    (Adam densifies the factors)."""
+    torch.manual_seed(seed)
+    net = ODENet("cpu", N, explicit_time=False, neurons=H).float()
+    if dense_std is not None:
+        with torch.no_grad():
+            for lin in (net.net_sums.linear_out, net.net_prods.linear_out, net.net_alpha_combine.linear_out):
+                lin.weight.normal_(0.0, dense_std)
+            net.net_sums.linear_out.bias.uniform_(-0.2, 0.2)
+            net.net_prods.linear_out.bias.uniform_(-0.2, 0.2)
+    if neg_g_frac > 0:
+        with torch.no_grad():
+            m = torch.rand(1, N) < neg_g_frac
+            net.gene_multipliers[m] = -net.gene_multipliers[m]  # relu() clamps these genes to 0
+    return net
+
+
+def params_np(net):
+    return {
+        "Ws": net.net_sums.linear_out.weight.detach().numpy().copy(),
+        "bs": net.net_sums.linear_out.bias.detach().numpy().copy(),
+        "Wp": net.net_prods.linear_out.weight.detach().numpy().copy(),
+        "bp": net.net_prods.linear_out.bias.detach().numpy().copy(),
+        "Wa": net.net_alpha_combine.linear_out.weight.detach().numpy().copy(),
+        "g": net.gene_multipliers.detach().numpy().reshape(-1).copy(),
+    }
+
+
+def grads_np(net, prefix="grad_"):
+    def g(p):
+        return (torch.zeros_like(p) if p.grad is None else p.grad).detach().numpy().copy()
+
+    return {
+        prefix + "Ws": g(net.net_sums.linear_out.weight),
+        prefix + "bs": g(net.net_sums.linear_out.bias),
+        prefix + "Wp": g(net.net_prods.linear_out.weight),
+        prefix + "bp": g(net.net_prods.linear_out.bias),
+        prefix + "Wa": g(net.net_alpha_combine.linear_out.weight),
+        prefix + "g": g(net.gene_multipliers).reshape(-1),
+    }
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote %-28s %6.1f KB  keys=%d" % (name + ".npz", os.path.getsize(path) / 1024, len(arrs)))
+
+
+def pfx(d, p):
+    return {p + k: v for k, v in d.items()}
+
+
+# ---------------------------------------------------------------- G1 / G2
+def g1_g2():
+    out = {}
+    cases = [("sparse", 48, 8, None, 0.0), ("dense", 48, 8, 0.15, 0.25), ("odd", 37, 5, 0.2, 0.2)]
+    for name, N, H, std, neg in cases:
+        net = make_net(N, H, seed=11, dense_std=std, neg_g_frac=neg)
+        torch.manual_seed(5)
+        y = torch.rand(6, 1, N) * 7 - 3  # [-3, 4]
+        y[0, 0, :4] = torch.tensor([0.5, 0.5 + 1e-7, 50.0, -50.0])  # kink + large magnitudes
+        y1 = torch.rand(1, N) * 1.2 - 0.1
+        f = net(torch.tensor(0.0), y).detach()
+        fp = net.prior_only_forward(torch.tensor(0.0), y).detach()
+        f1 = net(torch.tensor(0.0), y1).detach()
+        # VJP
+        yv = y.clone().requires_grad_(True)
+        cot = torch.randn(6, 1, N)
+        fv = net(torch.tensor(0.0), yv)
+        gr = torch.autograd.grad(fv, (yv,) + tuple(net.parameters()), cot)
+        names = [n for n, _ in net.named_parameters()]
+        gmap = dict(zip(names, gr[1:]))
+        # prior_only VJP
+        yv2 = y.clone().requires_grad_(True)
+        fv2 = net.prior_only_forward(torch.tensor(0.0), yv2)
+        gr2 = torch.autograd.grad(fv2, (yv2,) + tuple(net.parameters()), cot, allow_unused=True)
+        gmap2 = dict(zip(names, gr2[1:]))
+
+        def gm(m, N=N):
+            z = lambda k, shape: (m[k] if m[k] is not None else torch.zeros(shape)).numpy()
+            H_ = m["net_sums.linear_out.bias"].shape[0]
+            return {
+                "Ws": z("net_sums.linear_out.weight", (H_, N)), "bs": z("net_sums.linear_out.bias", (H_,)),
+                "Wp": z("net_prods.linear_out.weight", (H_, N)), "bp": z("net_prods.linear_out.bias", (H_,)),
+                "Wa": z("net_alpha_combine.linear_out.weight", (N, 2 * H_)),
+                "g": z("gene_multipliers", (1, N)).reshape(-1),
+            }
+
+        d = dict(y=y.numpy(), f=f.numpy(), f_prior=fp.numpy(), y1=y1.numpy(), f1=f1.numpy(), cot=cot.numpy(),
+                 vjp_y=gr[0].numpy(), vjp_y_prior=gr2[0].numpy())
+        d.update(pfx(params_np(net), "p_"))
+        d.update(pfx(gm(gmap), "vjp_"))
+        d.update(pfx(gm(gmap2), "vjpprior_"))
+        out.update(pfx(d, name + "/"))
+    save("g1_g2_rhs", **out)
+
+
+# ---------------------------------------------------------------- G3 / G4 helpers
+def run_adjoint(net, y0, t, method, G):
+    """loss = sum(G * odeint_adjoint(...)); returns sol, y0.grad, param grads."""
+    for p in net.parameters():
+        p.grad = None
+    y0 = y0.clone().requires_grad_(True)
+    sol = odeint_adjoint(net, y0, t, method=method)
+    (sol * G).sum().backward()
+    return sol.detach().numpy(), y0.grad.numpy().copy(), grads_np(net)
+
+
+def g3_fixed():
+    out = {}
+    N, H = 40, 6
+    net = make_net(N, H, seed=3, dense_std=0.12, neg_g_frac=0.15)
+    out.update(pfx(params_np(net), "p_"))
+    torch.manual_seed(7)
+    y0_single = torch.rand(1, N)
+    y0_batch = torch.rand(5, 1, N) * 1.5 - 0.25
+    t2 = torch.tensor([0.0, 2.0])
+    t5 = torch.tensor([0.0, 2.0, 3.0, 7.0, 9.0])  # simulator time stamps
+    t5_64 = t5.double() * 0.1 + 0.013
+    t_dec = torch.tensor([1.0, 0.6, 0.1])
+    out.update(y0_single=y0_single.numpy(), y0_batch=y0_batch.numpy(), t2=t2.numpy(), t5=t5.numpy(),
+               t5_64=t5_64.numpy(), t_dec=t_dec.numpy())
+    for method in ("euler", "midpoint", "rk4"):
+        for tname, t in (("t2", t2), ("t5", t5), ("t5_64", t5_64), ("t_dec", t_dec)):
+            for yname, y0 in (("single", y0_single), ("batch", y0_batch)):
+                with torch.no_grad():
+                    sol = odeint(net, y0, t, method=method)
+                key = "%s/%s/%s/" % (method, tname, yname)
+                out[key + "sol"] = sol.numpy()
+                if tname in ("t2", "t5", "t_dec"):
+                    torch.manual_seed(13)
+                    G = torch.randn(sol.shape)
+                    s2, gy0, gp = run_adjoint(net, y0, t, method, G)
+                    assert np.array_equal(s2, sol.numpy())
+                    out[key + "G"] = G.numpy()
+                    out[key + "grad_y0"] = gy0
+                    out.update(pfx(gp, key))
+    save("g3_fixed", **out)
+
+
+def g4_dopri5():
+    out = {}
+    N, H = 32, 6
+    net = make_net(N, H, seed=21, dense_std=0.2, neg_g_frac=0.1)
+    out.update(pfx(params_np(net), "p_"))
+    torch.manual_seed(9)
+    y0_single = torch.rand(1, N) * 1.4 - 0.2
+    y0_batch = torch.rand(4, 1, N) * 1.4 - 0.2
+    t2 = torch.tensor([0.0, 1.5])
+    t4 = torch.tensor([0.0, 0.5, 1.25, 3.0])
+    t10_64 = torch.arange(0, 1, 0.1, dtype=torch.float64)
+    t_dec = torch.tensor([2.0, 1.0, 0.25])
+    out.update(y0_single=y0_single.numpy(), y0_batch=y0_batch.numpy(), t2=t2.numpy(), t4=t4.numpy(),
+               t10_64=t10_64.numpy(), t_dec=t_dec.numpy())
+    for tname, t in (("t2", t2), ("t4", t4), ("t10_64", t10_64), ("t_dec", t_dec)):
+        for yname, y0 in (("single", y0_single), ("batch", y0_batch)):
+            with torch.no_grad():
+                sol = odeint(net, y0, t)  # default method = dopri5, rtol 1e-7, atol 1e-9
+            key = "%s/%s/" % (tname, yname)
+            out[key + "sol"] = sol.numpy()
+            if tname != "t10_64":
+                torch.manual_seed(17)
+                G = torch.randn(sol.shape)
+                s2, gy0, gp = run_adjoint(net, y0, t, "dopri5", G)
+                out[key + "G"] = G.numpy()
+                out[key + "grad_y0"] = gy0
+                out.update(pfx(gp, key))
+            # fp64 tight-tolerance "truth" of the same ODE
+            net64 = make_net(N, H, seed=21, dense_std=0.2, neg_g_frac=0.1).double()
+            with torch.no_grad():
+                truth = odeint(net64, y0.double(), t.double(), rtol=1e-12, atol=1e-14)
+            out[key + "truth64"] = truth.numpy()
+    # per-sample loop (the training-loop semantics, train_insilico.py:128-130)
+    tb = torch.tensor([[0.0, 0.7], [0.3, 1.9], [1.0, 1.2], [0.0, 2.5]])
+    preds = []
+    for p in net.parameters():
+        p.grad = None
+    y0b = y0_batch.clone().requires_grad_(True)
+    for time, yp in zip(tb, y0b):
+        preds.append(odeint_adjoint(net, yp, time)[1])
+    pred = torch.stack(preds)
+    torch.manual_seed(19)
+    G = torch.randn(pred.shape)
+    (pred * G).sum().backward()
+    out.update({"loop/t": tb.numpy(), "loop/pred": pred.detach().numpy(), "loop/G": G.numpy(),
+                "loop/grad_y0": y0b.grad.numpy().copy()})
+    out.update(pfx(grads_np(net), "loop/"))
+    save("g4_dopri5", **out)
+
+
+# ---------------------------------------------------------------- G5
+def load_reference_training_step():
+    """The reference's train_insilico.py is a script (argparse at import); lift its
+    `training_step` function object out by AST and bind it to the reference's odeint_adjoint,
+    exactly as the script does (`from torchdiffeq import odeint_adjoint as odeint`, :15-18)."""
+    src = open(os.path.join(REF, "train_insilico.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "training_step"]
+    assert len(fn) == 1
+    mod = ast.Module(body=fn, type_ignores=[])
+    ns = {"torch": torch, "odeint": odeint_adjoint}
+    exec(compile(mod, "<reference train_insilico.py:training_step>", "exec"), ns)
+    return ns["training_step"]
+
+
+class FakeHandler:
+    """Minimal stand-in for DataHandler.get_batch (datahandler.py:87-93): fixed tensors."""
+    device = "cpu"
+
+    def __init__(self, batch, t, target):
+        self.b = (batch, t, target)
+
+    def get_batch(self, bs):
+        return self.b
+
+
+def g5_training_step():
+    training_step = load_reference_training_step()
+    out = {}
+    N, H, B, K = 36, 6, 4, 32
+    for method in ("dopri5", "rk4"):
+        for lam in (0.99, 1.0):
+            net = make_net(N, H, seed=33, dense_std=0.15, neg_g_frac=0.1)
+            torch.manual_seed(41)
+            batch = torch.rand(B, 1, N)
+            t = torch.tensor([[0.0, 2.0], [2.0, 3.0], [3.0, 7.0], [7.0, 9.0]]) * 0.25
+            target = batch + 0.1 * torch.randn(B, 1, N)
+            X = torch.rand(K, 1, N) - 0.5
+            Pm = (torch.rand(N, N) < 0.03).float() * torch.sign(torch.randn(N, N))
+            prior_grad = torch.matmul(X, Pm)  # train_insilico.py:209-210
+            lr = 1e-3
+            opt = torch.optim.Adam([  # train_insilico.py:244-253
+                {"params": net.net_sums.linear_out.weight}, {"params": net.net_sums.linear_out.bias},
+                {"params": net.net_prods.linear_out.weight}, {"params": net.net_prods.linear_out.bias},
+                {"params": net.net_alpha_combine.linear_out.weight},
+                {"params": net.gene_multipliers, "lr": 5 * lr}], lr=lr, weight_decay=0)
+            key = "%s/lam%g/" % (method, lam)
+            out.update(pfx(params_np(net), key + "p_"))
+            # predictions (the function does not return them): same loop, no grad
+            with torch.no_grad():
+                pred = torch.stack([odeint(net, bp, tt, method=method)[1] for tt, bp in zip(t, batch)])
+            loss_data, loss_prior = training_step(net, FakeHandler(batch, t, target), opt, method, B, False,
+                                                  False, X, prior_grad, lam)
+            out.update({key + "batch": batch.numpy(), key + "t": t.numpy(), key + "target": target.numpy(),
+                        key + "X": X.numpy(), key + "prior_grad": prior_grad.numpy(), key + "pred": pred.numpy(),
+                        key + "loss_data": loss_data.item(), key + "loss_prior": loss_prior.item(),
+                        key + "lr": lr})
+            out.update(pfx(grads_np(net), key))
+            out.update(pfx(params_np(net), key + "after_"))
+    save("g5_training_step", **out)
+
+
+# ---------------------------------------------------------------- G6
+def g6_controller():
+    out = {}
+    torch.manual_seed(2)
+    n = 50
+    x = torch.randn(n)
+    out["norm/x"] = x.numpy()
+    out["norm/rms"] = ref_misc._rms_norm(x).item()
+    shapes = [torch.Size(()), torch.Size((1, 12)), torch.Size((1, 12)), torch.Size((25,))]
+    out["norm/blocks"] = np.array([1, 12, 12, 25])
+    out["norm/mixed"] = float(ref_misc._mixed_linf_rms_norm(shapes)(x))
+    # _optimal_step_size
+    ers = [0.0, 1e-4, 0.3, 0.999, 1.0, 1.7, 50.0, 1e6]
+    res = []
+    for er in ers:
+        r = ref_misc._optimal_step_size(torch.tensor(0.125, dtype=torch.float64), torch.tensor(er, dtype=torch.float32),
+                                        torch.tensor(0.9, dtype=torch.float64), torch.tensor(10.0, dtype=torch.float64),
+                                        torch.tensor(0.2, dtype=torch.float64), 5)
+        res.append(float(r))
+    out["step/error_ratio"] = np.array(ers, np.float32)
+    out["step/dt_next"] = np.array(res, np.float64)
+    # interpolation
+    y0, y1, ym, f0, f1 = [torch.randn(n) for _ in range(5)]
+    dt = torch.tensor(0.37)
+    coef = ref_interp._interp_fit(y0, y1, ym, f0, f1, dt)
+    out.update({"interp/y0": y0.numpy(), "interp/y1": y1.numpy(), "interp/ym": ym.numpy(), "interp/f0": f0.numpy(),
+                "interp/f1": f1.numpy(), "interp/dt": dt.item(), "interp/coef": torch.stack(coef).numpy()})
+    t0, t1 = torch.tensor(1.0, dtype=torch.float64), torch.tensor(1.37, dtype=torch.float64)
+    ts = [1.0, 1.1, 1.2345, 1.37]
+    out["interp/ts"] = np.array(ts)
+    out["interp/vals"] = np.stack([ref_interp._interp_evaluate(coef, t0, t1, torch.tensor(tt, dtype=torch.float64)).numpy()
+                                   for tt in ts])
+    # _select_initial_step + error ratio on a real net
+    N, H = 24, 4
+    net = make_net(N, H, seed=8, dense_std=0.2)
+    out.update(pfx(params_np(net), "init/p_"))
+    yy = torch.rand(1, N)
+    rtol = torch.tensor(1e-7, dtype=torch.float64)
+    atol = torch.tensor(1e-9, dtype=torch.float64)
+    with torch.no_grad():
+        func = lambda t, y: net(t.type_as(y), y)
+        h = ref_misc._select_initial_step(func, torch.tensor(0.0, dtype=torch.float64), yy, 4, rtol, atol,
+                                          ref_misc._rms_norm)
+    out["init/y0"] = yy.numpy()
+    out["init/h"] = float(h)
+    e, a, b = torch.randn(n) * 1e-7, torch.randn(n), torch.randn(n)
+    out.update({"ratio/err": e.numpy(), "ratio/y0": a.numpy(), "ratio/y1": b.numpy(),
+                "ratio/value": float(ref_misc._compute_error_ratio(e, rtol, atol, a, b, ref_misc._rms_norm))})
+    save("g6_controller", **out)
+
+
+# ---------------------------------------------------------------- G7
+def read_ref_csv(path, n_pairs):
+    """csvreader.readcsv format (csvreader.py:13-56): row0 = dim,ntraj; per trajectory `dim`
+    expression rows then one time row."""
+    import csv
+    with open(path) as fh:
+        rows = list(csv.reader(fh))
+    dim, ntraj = int(float(rows[0][0])), int(float(rows[0][1]))
+    expr = np.array([[float(v) if v != "" else np.nan for v in r] for r in rows[1:1 + dim]], np.float32)  # [dim, T]
+    tt = np.array([float(v) if v != "" else np.nan for v in rows[1 + dim]], np.float32)
+    return expr.T[: n_pairs + 1].copy(), tt[: n_pairs + 1].copy(), dim
+
+
+def g7_realdata():
+    out = {}
+    files = {
+        "yeast": "/root/reference/pramila_yeast_data/clean_data/pramila_500genes_1sample_24T.csv",
+        "breast": "/root/reference/breast_cancer_data/clean_data/desmedt_500genes_1sample_178T.csv",
+    }
+    for name, path in files.items():
+        Y, tt, dim = read_ref_csv(path, 2)
+        NG = 64  # first 64 genes keep the fixture small
+        Y = Y[:, :NG]
+        net = make_net(NG, 8, seed=77, dense_std=0.1)
+        key = name + "/"
+        out.update(pfx(params_np(net), key + "p_"))
+        out[key + "Y"] = Y
+        out[key + "t"] = tt
+        for i in range(2):
+            y0 = torch.from_numpy(Y[i:i + 1])
+            t = torch.from_numpy(tt[i:i + 2])
+            torch.manual_seed(23 + i)
+            G = torch.randn(2, 1, NG)
+            sol, gy0, gp = run_adjoint(net, y0, t, "dopri5", G)
+            out[key + "pair%d/sol" % i] = sol
+            out[key + "pair%d/G" % i] = G.numpy()
+            out[key + "pair%d/grad_y0" % i] = gy0
+            out.update(pfx(gp, key + "pair%d/" % i))
+    save("g7_realdata", **out)
+
+
+if __name__ == "__main__":
+    g1_g2()
+    g3_fixed()
+    g4_dopri5()
+    g5_training_step()
+    g6_controller()
+    g7_realdata()
