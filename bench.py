@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the PHOENIX NeuralODE hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic trajectories:
+    forward  odeint(ODENet, y0[B,1,N], t[B,2])       (one persistent launch, all samples)
+  + backward OdeintAdjointMethod.backward            (one persistent launch, all samples)
+  + (N GPUs > 1) one flat RCCL all-reduce of the P = 4HN+2H+N gradient floats.
+Default workload = BASELINE.json config C4 (the one the north-star target is quoted on):
+breast-cancer scale N=11165 genes, H=40, 256 trajectory intervals per GPU, dopri5 rtol 1e-7 / atol 1e-9.
+Weak scaling: every rank integrates its own 256 trajectories (no data-path collective).
+
+Metric: gene x trajectory RHS evaluations per second = sum over samples of (forward NFE + augmented NFE) * N / time.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N, H, B per GPU, method, t-row, y0 sampler, description)
+    "breast": dict(N=11165, H=40, B=256, method="dopri5", t=[0.0, 0.0051],
+                   desc="C4 breast_cancer ~11k-gene pseudotime, 256 trajectory intervals/GPU, dopri5 + adjoint"),
+    "insilico": dict(N=350, H=40, B=1024, method="rk4", t=[0.0, 2.0, 3.0, 7.0, 9.0],
+                     desc="C2 in-silico 350-gene sim, 1024 trajectories x 4 intervals, fused 3/8-rule rk4 + adjoint"),
+    "yeast": dict(N=2000, H=120, B=23, method="dopri5", t=[0.0, 5.0],
+                  desc="C3 yeast ~2000-gene oscillatory, 23 pairs, dopri5 + adjoint"),
+    "bcell": dict(N=14691, H=200, B=256, method="dopri5", t=[0.0, 1.0],
+                  desc="C5 B-cell ~15k-gene, H=200, 256 trajectories/GPU, dopri5 + adjoint"),
+}
+
+
+def make_problem(wl, device, seed):
+    import phoenix_amd
+    N, H, B = wl["N"], wl["H"], wl["B"]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    net = phoenix_amd.ODENet("cpu", N, neurons=H)
+    with torch.no_grad():   # trained-like dense factors (Adam densifies the 95%-sparse init), SURVEY 8d
+        for lin in (net.net_sums.linear_out, net.net_prods.linear_out, net.net_alpha_combine.linear_out):
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.05)
+        net.gene_multipliers.copy_(torch.rand(1, N, generator=g))
+    net = net.to(device)
+    if wl is WORKLOADS["yeast"]:
+        y0 = (torch.randn(B, 1, N, generator=g) * 0.4).clamp_(-2.5, 4.0)
+    else:
+        y0 = (torch.randn(B, 1, N, generator=g) * 0.15 + 0.5).clamp_(0.03, 1.07)
+    t = torch.tensor(wl["t"], dtype=torch.float32).repeat(B, 1)
+    return net, y0.to(device), t.to(device)
+
+
+def one_step(net, y0, t, G, method, world):
+    import phoenix_amd
+    from phoenix_amd import parallel
+    for p in net.parameters():
+        p.grad = None
+    y = y0.detach().requires_grad_(True)
+    sol = phoenix_amd.odeint_adjoint(net, y, t, method=method)
+    (sol * G).sum().backward()
+    if world > 1:
+        parallel.allreduce_grads(net)
+    return sol
+
+
+def cpu_baseline(wl, net, y0, t, G, seconds_budget=20.0):
+    """The CPU oracle (a port of the reference's algorithm; the Python reference cannot travel to the GPU
+    box) on a bounded sample of the same workload, reference-shaped: per-sample loop, theta block in the
+    adjoint norm, OpenMP across samples on all host cores."""
+    from oracle import oracle as orc
+    orc.build()
+    P = lambda x: x.detach().cpu().numpy()
+    onet = orc.Net(P(net.net_sums.linear_out.weight), P(net.net_sums.linear_out.bias),
+                   P(net.net_prods.linear_out.weight), P(net.net_prods.linear_out.bias),
+                   P(net.net_alpha_combine.linear_out.weight), P(net.gene_multipliers))
+    N = wl["N"]
+    cores = os.cpu_count() or 1
+    y = P(y0).reshape(-1, N)
+    tt = P(t)
+    T = tt.shape[1]
+    Gn = P(G).reshape(T, -1, N).transpose(1, 0, 2)
+
+    def run(nsamp):
+        t0 = time.perf_counter()
+        sol, nfe_f, _ = orc.odeint_per_sample(onet, y[:nsamp], tt[:nsamp], method=wl["method"], nthreads=cores,
+                                              return_stats=True)
+        _, _, nfe_b, _ = orc.adjoint_backward_per_sample(onet, tt[:nsamp], sol, np.ascontiguousarray(Gn[:nsamp]),
+                                                         method=wl["method"], theta_in_norm=True, nthreads=cores,
+                                                         return_stats=True)
+        return time.perf_counter() - t0, nfe_f, nfe_b
+
+    nsamp = min(cores, y.shape[0])
+    dt, nf, nb = run(nsamp)                     # calibration pass (also the warm-up)
+    scale = max(1, int(seconds_budget / max(dt, 1e-3)))
+    nsamp2 = min(y.shape[0], nsamp * scale)
+    if nsamp2 > nsamp:
+        dt, nf, nb = run(nsamp2)
+        nsamp = nsamp2
+    return {"value": (nf + nb) * N / dt, "unit": "gene*trajectory RHS evals/s", "cores": cores, "kind": "port",
+            "sample": "%d of %d trajectories, forward + adjoint, per-sample loop, %.1f s" % (nsamp, y.shape[0], dt),
+            "nfe_forward": int(nf), "nfe_augmented": int(nb)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="breast", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import phoenix_amd  # noqa: F401  (fails loudly if the HIP library is missing)
+    from phoenix_amd import engine
+
+    wl = WORKLOADS[args.workload]
+    N, H, B = wl["N"], wl["H"], wl["B"]
+    net, y0, t = make_problem(wl, device, seed=rank)          # every rank its own trajectories
+    if world > 1:   # replicas share parameters
+        import torch.distributed as dist
+        for p in net.parameters():
+            dist.broadcast(p.data, 0)
+    T = t.shape[1]
+    gg = torch.Generator(device="cpu").manual_seed(100 + rank)
+    G = (torch.randn(T, B, 1, N, generator=gg) / (B * N)).to(device)   # cotangent of a mean-type loss
+    G[0].zero_()
+
+    def sync_all():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(net, y0, t, G, wl["method"], world)
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(net, y0, t, G, wl["method"], world)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        import torch.distributed as dist
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- per-kernel timing with HIP events on the launch stream + NFE accounting (rank-local)
+    p = engine.Params(net.net_sums.linear_out.weight, net.net_sums.linear_out.bias, net.net_prods.linear_out.weight,
+                      net.net_prods.linear_out.bias, net.net_alpha_combine.linear_out.weight, net.gene_multipliers)
+    from phoenix_amd import _lib
+    y2 = y0.reshape(B, N).contiguous()
+    t64 = t.double().contiguous()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fwd_ms, adj_ms = [], []
+    nrep = max(3, min(args.steps, 10))
+    for _ in range(nrep):
+        ev[0].record()
+        sol, status, nfe_f, nsteps_f = engine.solve_forward(p, y2, t64, wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7,
+                                                            1e-9, True, True)
+        ev[1].record()
+        adj, grads, st2, nfe_b, nsteps_b = engine.solve_adjoint(p, t64, sol, G.reshape(T, B, N).contiguous(),
+                                                                wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9,
+                                                                True, True)
+        ev[2].record()
+        torch.cuda.synchronize()
+        fwd_ms.append(ev[0].elapsed_time(ev[1]))
+        adj_ms.append(ev[1].elapsed_time(ev[2]))
+    assert int(status.max()) == 0 and int(st2.max()) == 0
+    nfe_fwd = int(nfe_f.sum().item())
+    nfe_aug = int(nfe_b.sum().item())
+    fwd_ms_avg, adj_ms_avg = float(np.mean(fwd_ms)), float(np.mean(adj_ms))
+
+    # whole-job value
+    evals_per_step = (nfe_fwd + nfe_aug) * N      # gene x trajectory evaluations on this rank
+    if world > 1:
+        import torch.distributed as dist
+        te = torch.tensor([float(evals_per_step)], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.SUM)
+        total_evals_per_step = float(te.item())
+    else:
+        total_evals_per_step = float(evals_per_step)
+    value = total_evals_per_step * args.steps / elapsed
+
+    if rank == 0:
+        P = 4 * H * N + 2 * H + N
+        # ALGORITHMIC bytes: per RHS eval of a batch of B: 4P + 8BN; per augmented eval: 2*4P + 16BN.
+        # Units per launch = batch-evaluations = (sum_b nfe_b) / B.
+        alg_fwd = (nfe_fwd / B) * (4 * P + 8 * B * N)
+        alg_adj = (nfe_aug / B) * (8 * P + 16 * B * N)
+        dom = "k_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k_solve_fwd"
+        alg, ms = (alg_adj, adj_ms_avg) if dom == "k_solve_adj" else (alg_fwd, fwd_ms_avg)
+        achieved = alg / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None,
+                    "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
+                    "forward": {"launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
+                                "batch_evals": nfe_fwd / B},
+                    "adjoint": {"launch_ms": adj_ms_avg, "GBps": alg_adj / (adj_ms_avg * 1e-3) / 1e9,
+                                "batch_evals": nfe_aug / B}}
+        out = {
+            "metric": "ODE-RHS evals/sec (genes x trajectories)", "value": value,
+            "unit": "gene*trajectory RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "genes": N, "hidden": H, "trajectories_per_gpu": B,
+                       "method": wl["method"], "rtol": 1e-7, "atol": 1e-9, "time_points": wl["t"],
+                       "parallelism": "trajectory-sharded x%d, flat gradient all-reduce" % world,
+                       "nfe_forward_per_step": nfe_fwd, "nfe_augmented_per_step": nfe_aug},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(wl, net, y0, t, G)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/*
+ * phoenix_hip.h -- C ABI of the MI355X-native PHOENIX NeuralODE engine (libphoenix_hip.so).
+ *
+ * The reference (QuackenbushLab/phoenix) is pure Python and has NO plugin / FFI interface; its
+ * boundary for this path is the Python pair
+ *     odeint(func, y0, t, rtol, atol, method, options)           torchdiffeq/_impl/odeint.py:30
+ *     odeint_adjoint(...)                                          torchdiffeq/_impl/adjoint.py:165
+ * plus the `func(t, y)` protocol implemented by ODENet (odenet.py:85-98).  This header is the
+ * native boundary a maintainer binds *underneath* those two functions (INTEGRATION.md shows the
+ * ctypes stub); phoenix_amd/ is exactly such a binding.  Each entry point names the reference
+ * code it replaces.  All paths are relative to /root/reference/ode_net/code/.
+ *
+ * Conventions
+ *  - plain pointers + sizes; every data pointer is a DEVICE pointer unless marked HOST.
+ *  - the caller owns all memory (parameters, states, outputs, workspace); the library never
+ *    allocates or frees device memory and keeps no pointer past the call.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it; no call synchronises.
+ *  - every function returns a phx_status (0 = enqueued OK).  Solver-level failures (the
+ *    reference's AssertionErrors) are reported per trajectory in the `status` output array.
+ *  - fp32 state, fp64 time scalars, exactly like the reference (rk_common.py:115-131).
+ */
+#ifndef PHOENIX_HIP_H
+#define PHOENIX_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHX_ABI_VERSION 1
+
+/* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
+ *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
+ *   Wp  [H, N]   net_prods.linear_out.weight           (reference layout as is)
+ *   WaT [2H, N]  net_alpha_combine.linear_out.weight TRANSPOSED (reference stores [N, 2H])
+ *   bs, bp [H]   biases;   g [N] gene_multipliers ([1,N] in the reference)                  */
+typedef struct phx_params {
+    const float *Ws, *bs, *Wp, *bp, *WaT, *g;
+    int N, H;
+} phx_params;
+
+/* Gradient buffers with the same shapes/layouts; the engine ACCUMULATES (+=) into them. */
+typedef struct phx_grads {
+    float *Ws, *bs, *Wp, *bp, *WaT, *g;
+} phx_grads;
+
+/* torchdiffeq SOLVERS entries on the BASELINE path (odeint.py:14-27) */
+enum phx_method { PHX_EULER = 0, PHX_MIDPOINT = 1, PHX_RK4 = 2 /* 3/8 rule */, PHX_DOPRI5 = 3 };
+
+/* step control of a batch */
+enum phx_control {
+    PHX_CTRL_SHARED = 0,        /* reference odeint on y0[B,1,N]: one controller, rms over B*N */
+    PHX_CTRL_PER_TRAJECTORY = 1 /* reference training loop: B independent odeint calls        */
+};
+
+enum phx_status {
+    PHX_OK = 0,
+    PHX_ERR_MAX_STEPS = 1,    /* AssertionError 'max_num_steps exceeded'        rk_common.py:154 */
+    PHX_ERR_DT_UNDERFLOW = 2, /* AssertionError 'underflow in dt'               rk_common.py:175 */
+    PHX_ERR_NONFINITE = 3,    /* AssertionError 'non-finite values in state y'  rk_common.py:176 */
+    PHX_ERR_BAD_ARG = 4,
+    PHX_ERR_WORKSPACE = 5,    /* workspace too small */
+    PHX_ERR_LAUNCH = 6,       /* HIP launch failure */
+    PHX_ERR_SYNC_TIMEOUT = 7  /* in-kernel grid barrier timed out (kernel aborted itself) */
+};
+
+typedef struct phx_solve_opts {
+    int method;         /* phx_method */
+    int control;        /* phx_control */
+    double rtol, atol;  /* odeint defaults 1e-7 / 1e-9 (odeint.py:30) */
+    int t_per_sample;   /* 0: t is [T] shared;  1: t is [B, T] (training loop: t[b] = (t_i, t_{i+1})) */
+    int t_is_f32;       /* the caller's t tensor was float32 (fixed-grid dt is then formed in fp32) */
+    long long max_num_steps; /* <=0: 2^31-1 like the reference (rk_common.py:110) */
+} phx_solve_opts;
+
+int phx_abi_version(void);
+const char *phx_status_string(int status);
+/* number of CUs the engine sizes its persistent grids for (0 if no device) */
+int phx_device_cus(void);
+
+/* Workspace size (bytes) for one call of entry point `op` with this shape. */
+enum phx_op { PHX_OP_RHS_FORWARD = 0, PHX_OP_RHS_VJP = 1, PHX_OP_ODEINT = 2, PHX_OP_ADJOINT = 3 };
+size_t phx_workspace_bytes(int op, int N, int H, int B, int T);
+
+/* Replaces ODENet.forward / prior_only_forward (odenet.py:85-98): out[B,N] = f(y[B,N]). */
+int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int prior_only,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces torch.autograd.grad through ODENet.forward (adjoint.py:116-119; and the autograd
+ * backward of prior_only_forward, train_insilico.py:134-138):
+ *   vjp_y[B,N] = cot^T df/dy   (overwritten; may be NULL)
+ *   grads     += cot^T df/dtheta summed over B  (may be NULL)
+ *   f_out[B,N] = f(y)          (may be NULL)                                               */
+int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vjp_y,
+                const phx_grads *grads, float *f_out, int B, int prior_only, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* Replaces odeint(ODENet, y0, t, rtol, atol, method) (odeint.py:30-74; solvers.py:23-30,77-95;
+ * rk_common.py:39-228; fixed_grid.py:6-38; dopri5.py; misc.py:47-103; interp.py).
+ *   y0 [B,N]; t (double) [T] or [B,T] increasing or decreasing; sol [T,B,N] (sol[0] = y0).
+ *   status [B] (int, phx_status per trajectory), nfe [B] (int, RHS evaluations), nsteps [B].   */
+int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int T,
+               const phx_solve_opts *opts, float *sol, int *status, int *nfe, int *nsteps,
+               void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces OdeintAdjointMethod.backward (adjoint.py:32-162):
+ *   y_saved [T,B,N] forward outputs, grad_y [T,B,N] cotangents of every output time,
+ *   adj_y0 [B,N] (overwritten) = dL/dy0,   grads += dL/dtheta (summed over B).
+ * The parameter gradient is integrated as a quadrature with the solver's own weights (identical
+ * mathematics to the reference's P-sized augmented state, adjoint.py:86-87,127); the adaptive
+ * controller's norm covers the [t, y, adj_y] blocks (the reference also includes theta).      */
+int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int T,
+                                const phx_solve_opts *opts, const float *y_saved,
+                                const float *grad_y, float *adj_y0, const phx_grads *grads,
+                                int *status, int *nfe, int *nsteps, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

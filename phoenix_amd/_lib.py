@@ -1,0 +1,70 @@
+"""ctypes binding of the C ABI declared in include/phoenix_hip.h.
+
+There is NO fallback: if libphoenix_hip.so is missing the import fails loudly (build it with
+`python -m phoenix_amd.build` or `__graft_entry__.build()`), and every entry point requires a GPU."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class PhxParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("N", C.c_int), ("H", C.c_int)]
+
+
+class PhxGrads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")]
+
+
+class PhxSolveOpts(C.Structure):
+    _fields_ = [("method", C.c_int), ("control", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
+                ("t_per_sample", C.c_int), ("t_is_f32", C.c_int), ("max_num_steps", C.c_longlong)]
+
+
+EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
+           "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward")
+
+OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
+METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
+CTRL_SHARED, CTRL_PER_TRAJECTORY = 0, 1
+STATUS_TEXT = {
+    1: "max_num_steps exceeded",
+    2: "underflow in dt",
+    3: "non-finite values in state `y`",
+    4: "bad argument (t must be strictly increasing or decreasing)",
+    5: "workspace too small",
+    6: "HIP launch failure",
+    7: "in-kernel grid barrier timed out",
+}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "phoenix_amd: %s not found. The HIP engine is the only execution path (no CPU fallback); "
+            "build it with `python -m phoenix_amd.build`." % path)
+    lib = C.CDLL(path)
+    lib.phx_status_string.restype = C.c_char_p
+    lib.phx_workspace_bytes.restype = C.c_size_t
+    lib.phx_workspace_bytes.argtypes = [C.c_int] * 5
+    vp = C.c_void_p
+    lib.phx_rhs_forward.argtypes = [C.POINTER(PhxParams), vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]
+    lib.phx_rhs_vjp.argtypes = [C.POINTER(PhxParams), vp, vp, vp, C.POINTER(PhxGrads), vp, C.c_int, C.c_int, vp,
+                                C.c_size_t, vp]
+    lib.phx_odeint.argtypes = [C.POINTER(PhxParams), vp, vp, C.c_int, C.c_int, C.POINTER(PhxSolveOpts), vp, vp, vp,
+                               vp, vp, C.c_size_t, vp]
+    lib.phx_odeint_adjoint_backward.argtypes = [C.POINTER(PhxParams), vp, C.c_int, C.c_int, C.POINTER(PhxSolveOpts),
+                                                vp, vp, vp, C.POINTER(PhxGrads), vp, vp, vp, vp, C.c_size_t, vp]
+    assert lib.phx_abi_version() == 1
+    _LIB = lib
+    return lib

@@ -1,0 +1,984 @@
+// phx_engine.hip -- MI355X (gfx950) kernels + C ABI of the PHOENIX NeuralODE engine.
+//
+// What it replaces in the reference (paths relative to /root/reference/ode_net/code/):
+//   ODENet.forward / prior_only_forward                      odenet.py:85-98
+//   torch.autograd.grad through it (RHS VJP)                  torchdiffeq/_impl/adjoint.py:101-119
+//   odeint: fixed grid (euler, midpoint, rk4 = 3/8 rule)      solvers.py:77-95, fixed_grid.py:6-38, rk_common.py:96-103
+//   odeint: dopri5 adaptive + dense output                    rk_common.py:39-77,140-228, misc.py:47-103, interp.py
+//   OdeintAdjointMethod.backward                              adjoint.py:32-162
+//
+// Execution model: ONE persistent launch per solve.  The launch is a cooperative grid of at most
+// one 512-thread workgroup per CU; workgroups own (trajectory, 512-gene chunk) items for the
+// whole solve and meet at grid barriers only to exchange the hidden vector ([B,2H] forward,
+// [B,4H] augmented) and the controller scalars.  All RK stages, the error norm, accept/reject,
+// step-size control, dense output and (backward) the parameter-gradient quadrature run inside
+// that one launch -- no host round trip per step.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/phoenix_hip.h"
+#include "phx_device.hpp"
+
+using namespace phx;
+
+namespace {
+
+struct Net {
+    const float *Ws, *bs, *Wp, *bp, *WaT, *g;
+    int N, H;
+};
+
+struct Dims {
+    int N, H, B, T;
+    int NC;        // gene chunks per trajectory
+    int items;     // B * NC
+    int GB;        // trajectory groups of the parameter-gradient pass
+    int BG;        // trajectories per group
+    int Bc;        // number of step controllers (1 = shared, B = per trajectory)
+    long long BN;  // B * N
+    long long PP;  // padded size of one parameter-gradient partial
+};
+
+struct SolveCfg {
+    int method, control, t_per_sample, t_is_f32;
+    float rtol, atol;  // the reference multiplies fp32 tensors by these (cast to fp32)
+    long long max_steps;
+};
+
+// workspace views (device pointers)
+struct WS {
+    SyncBlock *sync;
+    double *rk_t0, *rk_t1, *dt, *xfin;
+    float *h0f, *dtf, *dtp, *sgn, *wq;  // dtp: fp32 dt of the step just taken; wq: [B][8] quadrature weights
+    int *out_idx, *done, *accept, *out_lo, *out_hi, *fin, *st, *nsteps, *nfe;
+    float *Y0, *A0, *YS, *AS;     // [B,N] each
+    float *KY, *KA;               // [S][B,N]
+    float *SA, *SL, *SQ, *SG;     // [S][B,N] stage data for the parameter-gradient pass
+    float *partial;               // [items][4H]
+    float *red;                   // [items][4]
+    float *Z, *DZ;                // [S][B][2H]
+    float *dtheta;                // [GB][PP]
+};
+
+struct Layout {
+    size_t total;
+    size_t sync, rk_t0, rk_t1, dt, xfin, h0f, dtf, dtp, sgn, wq, ints, Y0, A0, YS, AS, KY, KA, SA, SL, SQ, SG,
+        partial, red, Z, DZ, dtheta;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline Dims make_dims(int N, int H, int B, int T, int control)
+{
+    Dims d;
+    d.N = N; d.H = H; d.B = B; d.T = T;
+    d.NC = (N + CH - 1) / CH;
+    d.items = B * d.NC;
+    d.GB = std::min(B, 8);
+    d.BG = (B + d.GB - 1) / d.GB;
+    d.Bc = (control == PHX_CTRL_SHARED) ? 1 : B;
+    d.BN = (long long)B * N;
+    d.PP = (long long)align_up((size_t)4 * H * N + N + 2 * H, 4);
+    return d;
+}
+
+// nstate: number of [B,N] state vectors (Y0,YS / +A0,AS); nk: number of K stage slots kept for
+// y (and for adj when aug); nsd: number of stage-data slots (SA,SL,SQ,SG) ; grads: dtheta partials
+inline Layout make_layout(const Dims &d, int op)
+{
+    const bool solve = (op == PHX_OP_ODEINT || op == PHX_OP_ADJOINT);
+    const bool aug = (op == PHX_OP_RHS_VJP || op == PHX_OP_ADJOINT);
+    const int nk = solve ? MAXS : 0;
+    const int nsd = (op == PHX_OP_ADJOINT) ? MAXS : (op == PHX_OP_RHS_VJP ? 1 : 0);
+    const int nz = solve ? MAXS : 1;
+    Layout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t B = d.B, BN = (size_t)d.BN;
+    L.sync = take(sizeof(SyncBlock));
+    L.rk_t0 = take(8 * B); L.rk_t1 = take(8 * B); L.dt = take(8 * B); L.xfin = take(8 * B);
+    L.h0f = take(4 * B); L.dtf = take(4 * B); L.dtp = take(4 * B); L.sgn = take(4 * B); L.wq = take(4 * B * 8);
+    L.ints = take(4 * B * 9);
+    L.Y0 = take(solve ? 4 * BN : 0);
+    L.YS = take(solve ? 4 * BN : 0);
+    L.A0 = take(op == PHX_OP_ADJOINT ? 4 * BN : 0);
+    L.AS = take(op == PHX_OP_ADJOINT ? 4 * BN : 0);
+    L.KY = take(4 * BN * nk);
+    L.KA = take(op == PHX_OP_ADJOINT ? 4 * BN * nk : 0);
+    L.SA = take(4 * BN * nsd); L.SL = take(4 * BN * nsd); L.SQ = take(4 * BN * nsd); L.SG = take(4 * BN * nsd);
+    L.partial = take(4 * (size_t)d.items * (aug ? 4 : 2) * d.H);
+    L.red = take(4 * (size_t)d.items * 4);
+    L.Z = take(4 * B * 2 * d.H * nz);
+    L.DZ = take(aug ? 4 * B * 2 * d.H * nz : 0);
+    L.dtheta = take(aug ? 4 * (size_t)d.PP * d.GB : 0);
+    L.total = off;
+    return L;
+}
+
+inline WS make_ws(void *base, const Layout &L, const Dims &d)
+{
+    char *p = (char *)base;
+    WS w;
+    w.sync = (SyncBlock *)(p + L.sync);
+    w.rk_t0 = (double *)(p + L.rk_t0); w.rk_t1 = (double *)(p + L.rk_t1);
+    w.dt = (double *)(p + L.dt); w.xfin = (double *)(p + L.xfin);
+    w.h0f = (float *)(p + L.h0f); w.dtf = (float *)(p + L.dtf); w.dtp = (float *)(p + L.dtp);
+    w.sgn = (float *)(p + L.sgn);
+    w.wq = (float *)(p + L.wq);
+    int *ib = (int *)(p + L.ints);
+    const size_t B = d.B;
+    w.out_idx = ib; w.done = ib + B; w.accept = ib + 2 * B; w.out_lo = ib + 3 * B; w.out_hi = ib + 4 * B;
+    w.fin = ib + 5 * B; w.st = ib + 6 * B; w.nsteps = ib + 7 * B; w.nfe = ib + 8 * B;
+    w.Y0 = (float *)(p + L.Y0); w.A0 = (float *)(p + L.A0); w.YS = (float *)(p + L.YS); w.AS = (float *)(p + L.AS);
+    w.KY = (float *)(p + L.KY); w.KA = (float *)(p + L.KA);
+    w.SA = (float *)(p + L.SA); w.SL = (float *)(p + L.SL); w.SQ = (float *)(p + L.SQ); w.SG = (float *)(p + L.SG);
+    w.partial = (float *)(p + L.partial); w.red = (float *)(p + L.red);
+    w.Z = (float *)(p + L.Z); w.DZ = (float *)(p + L.DZ); w.dtheta = (float *)(p + L.dtheta);
+    return w;
+}
+
+// ========================================================================================
+// device phases of one RHS evaluation
+// ========================================================================================
+struct Lds {
+    float xa[CH], xl[CH], xq[CH];  // activations of the item's genes (phase A) / z, du, dv (phase C)
+    float red[NWAVE];
+    unsigned int flag;
+    unsigned int remaining;
+};
+
+// Phase A of item (b, c): per-gene activations, then the item's partial hidden sums
+//   rows [0,H): sum_n a[n] Ws[r][n];  [H,2H): sum_n l[n] Wp[r-H][n];  (AUG) [2H,4H): sum_n q[n] WaT[r-2H][n]
+template <bool AUG>
+__device__ __forceinline__ void phaseA(const Net &net, const Dims &d, const WS &w, int item, int c, float y,
+                                       float cot, bool valid, bool prior_only, int sd_slot, long long e, Lds &s)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = net.N, H = net.H;
+    const int n = c * CH + tid;
+    float a = 0.f, l = 0.f, q = 0.f;
+    if (valid) {
+        act_pair(y, a, l);
+        if (AUG) {
+            const float gm = net.g[n];
+            const float r = prior_only ? 1.0f : (gm > 0.f ? gm : 0.f);
+            q = cot * r;
+        }
+    }
+    __syncthreads();  // previous users of the LDS arrays are done
+    s.xa[tid] = a;
+    s.xl[tid] = l;
+    if (AUG) s.xq[tid] = q;
+    if (AUG && sd_slot >= 0 && valid) {
+        const long long o = (long long)sd_slot * d.BN + e;
+        w.SA[o] = a; w.SL[o] = l; w.SQ[o] = q;
+    }
+    __syncthreads();
+    const int R = AUG ? 4 * H : 2 * H;
+    float *pout = w.partial + (long long)item * R;
+    const int n0 = c * CH;
+    for (int r = wv; r < R; r += NWAVE) {
+        const float *x = (r < H) ? s.xa : ((r < 2 * H) ? s.xl : s.xq);
+        const float *Wrow = (r < H) ? net.Ws + (long long)r * N
+                          : (r < 2 * H) ? net.Wp + (long long)(r - H) * N
+                                        : net.WaT + (long long)(r - 2 * H) * N;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH / 64; ++i) {
+            const int nn = n0 + i * 64 + lane;
+            if (nn < N) acc += x[i * 64 + lane] * Wrow[nn];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) pout[r] = acc;
+    }
+}
+
+// Phase B: reduce the per-item partials of trajectory b in fixed chunk order -> hidden vector
+//   z[k<H] = u + bs ; z[k>=H] = exp(v + bp) ; (AUG) du = dz[k<H], dv = dz[k>=H] * p
+template <bool AUG>
+__device__ __forceinline__ void phaseB(const Net &net, const Dims &d, const WS &w, int slot, const int *skip,
+                                       bool shared_ctrl)
+{
+    const int H = net.H, K2 = 2 * H;
+    const int R = AUG ? 4 * H : 2 * H;
+    const long long total = (long long)d.B * K2;
+    for (long long idx = (long long)blockIdx.x * NT + threadIdx.x; idx < total; idx += (long long)gridDim.x * NT) {
+        const int b = (int)(idx / K2), k = (int)(idx % K2);
+        if (skip && skip[shared_ctrl ? 0 : b]) continue;
+        const float *pp = w.partial + (long long)b * d.NC * R;
+        float sacc = 0.f;
+        for (int c = 0; c < d.NC; ++c) sacc += pp[(long long)c * R + k];
+        sacc += (k < H) ? net.bs[k] : net.bp[k - H];
+        if (k >= H) sacc = expf(sacc);
+        const long long zo = ((long long)slot * d.B + b) * K2 + k;
+        w.Z[zo] = sacc;
+        if (AUG) {
+            float t = 0.f;
+            for (int c = 0; c < d.NC; ++c) t += pp[(long long)c * R + K2 + k];
+            if (k >= H) t *= sacc;
+            w.DZ[zo] = t;
+        }
+    }
+}
+
+// Phase C of item (b, c): expansion back to genes.
+//   j = sum_k z[k] WaT[k][n];  f = relu(g) (j - y)      (prior_only: f = j)
+//   (AUG) vjp = -q + (sum_h du[h] Ws[h][n]) a'(y) + (sum_h dv[h] Wp[h][n]) l'(y);  sg = cot (j - y) [g>0]
+template <bool AUG>
+__device__ __forceinline__ void phaseC(const Net &net, const Dims &d, const WS &w, int b, int c, int slot, float y,
+                                       float cot, bool valid, bool prior_only, float &f, float &vjp, float &sg,
+                                       Lds &s)
+{
+    const int tid = threadIdx.x;
+    const int N = net.N, H = net.H, K2 = 2 * H;
+    const int n = c * CH + tid;
+    __syncthreads();
+    const long long zo = ((long long)slot * d.B + b) * K2;
+    for (int k = tid; k < K2; k += NT) {
+        s.xa[k] = w.Z[zo + k];
+        if (AUG) s.xl[k] = w.DZ[zo + k];
+    }
+    __syncthreads();
+    f = 0.f; vjp = 0.f; sg = 0.f;
+    if (!valid) return;
+    float j = 0.f;
+    const float *wa = net.WaT + n;
+    for (int k = 0; k < K2; ++k) j += s.xa[k] * wa[(long long)k * N];
+    const float gm = net.g[n];
+    const float r = prior_only ? 1.0f : (gm > 0.f ? gm : 0.f);
+    f = prior_only ? j : r * (j - y);
+    if (AUG) {
+        float da_pre = 0.f, dl_pre = 0.f;
+        const float *ws = net.Ws + n, *wp = net.Wp + n;
+        for (int h = 0; h < H; ++h) {
+            da_pre += s.xl[h] * ws[(long long)h * N];
+            dl_pre += s.xl[H + h] * wp[(long long)h * N];
+        }
+        float da, dl;
+        act_grad(y, da, dl);
+        const float q = cot * r;
+        vjp = da_pre * da + dl_pre * dl;
+        if (!prior_only) {
+            vjp -= q;
+            sg = (gm > 0.f) ? cot * (j - y) : 0.f;
+        }
+    }
+}
+
+// Parameter-gradient pass: dtheta[bg] += sum_{b in group, stage s} wq(b,s) * vjp_theta(stage data).
+// Items: (gene chunk c, row tile, trajectory group bg); one lane per gene, RT rows in registers.
+//   Ws rows:  dWs[h][n]  += w du[h] a[n];   Wp rows: dWp[h][n] += w dv[h] l[n];
+//   WaT rows: dWaT[k][n] += w z[k] q[n];    g: dg[n] += w sg[n];  biases: dbs += w du, dbp += w dv.
+// wmode: 0 = weight 1, single stage (standalone VJP); 1 = wq array [B][8] (solver steps)
+__device__ __forceinline__ void phaseG(const Net &net, const Dims &d, const WS &w, int S, int wmode)
+{
+    const int tid = threadIdx.x;
+    const int N = net.N, H = net.H, K2 = 2 * H;
+    const int ntS = (H + RT - 1) / RT, ntA = (K2 + RT - 1) / RT;
+    const int NTILE = 2 * ntS + ntA + 1;  // Ws tiles, Wp tiles, WaT tiles, g tile
+    const long long oWs = 0, oWp = (long long)H * N, oWa = 2LL * H * N, og = 4LL * H * N, obs = og + N,
+                    obp = obs + H;
+    const int gene_items = d.NC * NTILE * d.GB;
+    const int total = gene_items + d.GB;  // + one bias item per group
+    for (int it = blockIdx.x; it < total; it += gridDim.x) {
+        if (it >= gene_items) {
+            // bias item of group bg: thread k < 2H
+            const int bg = it - gene_items;
+            const int b0 = bg * d.BG, b1 = min(d.B, b0 + d.BG);
+            if (tid < K2) {
+                float acc = 0.f;
+                for (int b = b0; b < b1; ++b)
+                    for (int sidx = 0; sidx < S; ++sidx) {
+                        const float wt = wmode ? w.wq[b * 8 + sidx] : 1.0f;
+                        if (wt != 0.f) acc += wt * w.DZ[((long long)sidx * d.B + b) * K2 + tid];
+                    }
+                float *dst = w.dtheta + (long long)bg * d.PP + (tid < H ? obs + tid : obp + (tid - H));
+                *dst += acc;
+            }
+            continue;
+        }
+        const int bg = it % d.GB;
+        const int tile = (it / d.GB) % NTILE;
+        const int c = it / (d.GB * NTILE);
+        const int n = c * CH + tid;
+        const bool valid = n < N;
+        const int b0 = bg * d.BG, b1 = min(d.B, b0 + d.BG);
+        // section of this tile
+        int sec, row0, nrows;
+        if (tile < ntS) { sec = 0; row0 = tile * RT; nrows = min(RT, H - row0); }
+        else if (tile < 2 * ntS) { sec = 1; row0 = (tile - ntS) * RT; nrows = min(RT, H - row0); }
+        else if (tile < 2 * ntS + ntA) { sec = 2; row0 = (tile - 2 * ntS) * RT; nrows = min(RT, K2 - row0); }
+        else { sec = 3; row0 = 0; nrows = 1; }
+        const float *X = (sec == 0) ? w.SA : (sec == 1) ? w.SL : (sec == 2) ? w.SQ : w.SG;
+        float acc[RT];
+#pragma unroll
+        for (int jx = 0; jx < RT; ++jx) acc[jx] = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            for (int sidx = 0; sidx < S; ++sidx) {
+                const float wt = wmode ? w.wq[b * 8 + sidx] : 1.0f;
+                if (wt == 0.f) continue;  // uniform
+                const float x = valid ? X[(long long)sidx * d.BN + (long long)b * N + n] : 0.f;
+                if (sec == 3) {
+                    acc[0] += wt * x;
+                } else {
+                    const float *coef = ((sec == 2) ? w.Z : w.DZ) + ((long long)sidx * d.B + b) * K2 +
+                                        (sec == 1 ? H : 0) + row0;
+#pragma unroll
+                    for (int jx = 0; jx < RT; ++jx)
+                        if (jx < nrows) acc[jx] += (wt * coef[jx]) * x;
+                }
+            }
+        }
+        if (valid) {
+            float *base = w.dtheta + (long long)bg * d.PP;
+            if (sec == 3) {
+                base[og + n] += acc[0];
+            } else {
+                const long long o = (sec == 0) ? oWs : (sec == 1) ? oWp : oWa;
+#pragma unroll
+                for (int jx = 0; jx < RT; ++jx)
+                    if (jx < nrows) base[o + (long long)(row0 + jx) * N + n] += acc[jx];
+            }
+        }
+    }
+}
+
+// ========================================================================================
+// standalone RHS / VJP evaluation (ODENet.forward, prior_only_forward and their backward)
+// ========================================================================================
+template <bool AUG>
+__global__ __launch_bounds__(NT) void k_eval(Net net, Dims d, WS w, const float *__restrict__ y,
+                                             const float *__restrict__ cot, float *out_f, float *out_vjp,
+                                             int prior_only, int want_grads, int *status)
+{
+    __shared__ Lds s;
+    GridSync gs{w.sync, gridDim.x, 0ull, false};
+    const int tid = threadIdx.x;
+    for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+        const int b = item / d.NC, c = item % d.NC;
+        const int n = c * CH + tid;
+        const bool valid = n < d.N;
+        const long long e = (long long)b * d.N + n;
+        const float yv = valid ? y[e] : 0.5f;
+        const float cv = (AUG && valid) ? cot[e] : 0.f;
+        phaseA<AUG>(net, d, w, item, c, yv, cv, valid, prior_only != 0, (AUG && want_grads) ? 0 : -1, e, s);
+    }
+    grid_barrier(gs, &s.flag);
+    phaseB<AUG>(net, d, w, 0, nullptr, false);
+    grid_barrier(gs, &s.flag);
+    for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+        const int b = item / d.NC, c = item % d.NC;
+        const int n = c * CH + tid;
+        const bool valid = n < d.N;
+        const long long e = (long long)b * d.N + n;
+        const float yv = valid ? y[e] : 0.5f;
+        const float cv = (AUG && valid) ? cot[e] : 0.f;
+        float f, vjp, sg;
+        phaseC<AUG>(net, d, w, b, c, 0, yv, cv, valid, prior_only != 0, f, vjp, sg, s);
+        if (valid) {
+            if (out_f) out_f[e] = f;
+            if (AUG && out_vjp) out_vjp[e] = vjp;
+            if (AUG && want_grads) w.SG[e] = sg;
+        }
+    }
+    if (AUG && want_grads) {
+        grid_barrier(gs, &s.flag);
+        phaseG(net, d, w, 1, 0);
+    }
+    if (blockIdx.x == 0 && tid == 0 && status) status[0] = gs.aborted ? PHX_ERR_SYNC_TIMEOUT : PHX_OK;
+}
+
+// grads += sum over trajectory groups of the partials (fixed order => deterministic)
+__global__ void k_reduce_grads(const float *__restrict__ dtheta, int GB, long long PP, int N, int H, float *gWs,
+                               float *gWp, float *gWaT, float *gg, float *gbs, float *gbp)
+{
+    const long long HN = (long long)H * N;
+    const long long total = 4 * HN + N + 2 * H;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        float sacc = 0.f;
+        for (int g = 0; g < GB; ++g) sacc += dtheta[(long long)g * PP + e];
+        if (e < HN) gWs[e] += sacc;
+        else if (e < 2 * HN) gWp[e - HN] += sacc;
+        else if (e < 4 * HN) gWaT[e - 2 * HN] += sacc;
+        else if (e < 4 * HN + N) gg[e - 4 * HN] += sacc;
+        else if (e < 4 * HN + N + H) gbs[e - 4 * HN - N] += sacc;
+        else gbp[e - 4 * HN - N - H] += sacc;
+    }
+}
+
+// ========================================================================================
+// solver helpers
+// ========================================================================================
+__device__ __forceinline__ const double *trow(const double *t, const Dims &d, const SolveCfg &cfg, int b)
+{
+    return cfg.t_per_sample ? t + (long long)b * d.T : t;
+}
+
+// stage input of the fixed-grid methods, in the reference's own operation order
+// (fixed_grid.py:13-27, rk_common.py:96-103)
+__device__ __forceinline__ float fixed_stage_input(int method, int st, float y0, const float *K, long long BN,
+                                                   long long e, float dt)
+{
+    const float third = (float)(1.0 / 3.0);
+    if (st == 0) return y0;
+    if (method == PHX_MIDPOINT) return y0 + K[e] * (0.5f * dt);
+    // rk4 = 3/8 rule
+    if (st == 1) return y0 + (dt * K[e]) * third;
+    if (st == 2) return y0 + dt * (K[BN + e] - K[e] * third);
+    return y0 + dt * ((K[e] - K[BN + e]) + K[2 * BN + e]);
+}
+__device__ __forceinline__ float fixed_final(int method, float y0, const float *K, long long BN, long long e,
+                                             float dt)
+{
+    if (method == PHX_EULER) return y0 + dt * K[e];
+    if (method == PHX_MIDPOINT) return y0 + dt * K[BN + e];
+    return y0 + (((K[e] + 3.0f * (K[BN + e] + K[2 * BN + e])) + K[3 * BN + e]) * dt) * 0.125f;
+}
+__device__ __forceinline__ int fixed_nstages(int method)
+{
+    return method == PHX_EULER ? 1 : (method == PHX_MIDPOINT ? 2 : 4);
+}
+// quadrature weight of stage st for the parameter gradient (same combination as fixed_final)
+__device__ __forceinline__ float fixed_weight(int method, int st, float dt)
+{
+    if (method == PHX_EULER) return dt;
+    if (method == PHX_MIDPOINT) return st == 1 ? dt : 0.f;
+    return ((st == 0 || st == 3) ? 1.0f : 3.0f) * dt * 0.125f;
+}
+
+// dopri5 stage input: y0 + k[:st] . (beta_st * dt)   (rk_common.py:64-66), fp32, j ascending
+__device__ __forceinline__ float dp_stage_input(int st, float y0, const float *K, long long BN, long long e,
+                                                float dt)
+{
+    float acc = 0.f;
+    for (int j = 0; j < st; ++j) acc += K[(long long)j * BN + e] * (DP_BETA[st - 1][j] * dt);
+    return y0 + acc;
+}
+__device__ __forceinline__ float dp_combo(const float *coef7, const float *K, long long BN, long long e, float dt)
+{
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc += K[(long long)j * BN + e] * (dt * coef7[j]);
+    return acc;
+}
+
+// quartic dense output (interp.py:1-47) at fraction x of the step
+struct InterpX { float x1, x2, x3, x4; };
+__device__ __forceinline__ InterpX make_interp_x(double x)
+{
+    InterpX r;
+    double xp = x;
+    r.x1 = (float)x;
+    xp *= x; r.x2 = (float)xp;
+    xp *= x; r.x3 = (float)xp;
+    xp *= x; r.x4 = (float)xp;
+    return r;
+}
+__device__ __forceinline__ float interp_eval(float y0, float y1, float ym, float f0, float f1, float dt,
+                                             const InterpX &ix)
+{
+    const float a = ((2.0f * dt) * (f1 - f0) - 8.0f * (y1 + y0)) + 16.0f * ym;
+    const float bb = ((dt * (5.0f * f0 - 3.0f * f1) + 18.0f * y0) + 14.0f * y1) - 32.0f * ym;
+    const float cc = ((dt * (f1 - 4.0f * f0) - 11.0f * y0) - 5.0f * y1) + 16.0f * ym;
+    const float dd = dt * f0;
+    float total = y0 + ix.x1 * dd;
+    total = total + ix.x2 * cc;
+    total = total + ix.x3 * bb;
+    total = total + ix.x4 * a;
+    return total;
+}
+
+// sum over the items of controller cb (fixed order, fp64) of red[..][slot]
+__device__ __forceinline__ double ctrl_sum(const Dims &d, const WS &w, int cb, bool shared, int slot)
+{
+    double acc = 0.0;
+    const int i0 = shared ? 0 : cb * d.NC, i1 = shared ? d.items : (cb + 1) * d.NC;
+    for (int i = i0; i < i1; ++i) acc += (double)w.red[(long long)i * 4 + slot];
+    return acc;
+}
+
+__device__ __forceinline__ float rms_from_sum(double sum, double count) { return sqrtf((float)(sum / count)); }
+
+// _select_initial_step, first half (misc.py:64-72)
+__device__ __forceinline__ float init_h0(float d0, float d1)
+{
+    if (d0 < 1e-5f || d1 < 1e-5f) return 1e-6f;
+    return (0.01f * d0) / d1;
+}
+// second half (misc.py:77-86), order + 1 = 5
+__device__ __forceinline__ double init_dt(float h0, float d1, float d2)
+{
+    float h1;
+    if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = tmaxf(1e-6f, h0 * 1e-3f);
+    else h1 = powf(0.01f / tmaxf(d1, d2), (float)(1.0 / 5.0));
+    return (double)tminf(100.0f * h0, h1);
+}
+
+// ========================================================================================
+// forward solve:  odeint(ODENet, y0, t)
+// ========================================================================================
+__global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCfg cfg, const float *__restrict__ y0,
+                                                  const double *__restrict__ t, float *sol, int *status, int *nfe,
+                                                  int *nsteps)
+{
+    __shared__ Lds s;
+    GridSync gs{w.sync, gridDim.x, 0ull, false};
+    const int tid = threadIdx.x;
+    const bool shared = cfg.control == PHX_CTRL_SHARED;
+    const long long gtid = (long long)blockIdx.x * NT + tid, gsize = (long long)gridDim.x * NT;
+    const int T = d.T;
+
+    // ---- init: controllers + state
+    for (long long cb = gtid; cb < d.Bc; cb += gsize) {
+        const double *tb = trow(t, d, cfg, (int)cb);
+        float sg = 1.0f;
+        int st = PHX_OK;
+        if (T >= 2) {
+            sg = (tb[1] < tb[0]) ? -1.0f : 1.0f;
+            for (int i = 0; i + 1 < T; ++i)
+                if (!((double)sg * tb[i + 1] > (double)sg * tb[i])) st = PHX_ERR_BAD_ARG;
+        }
+        w.sgn[cb] = sg;
+        w.st[cb] = st;
+        w.nsteps[cb] = 0;
+        w.nfe[cb] = 0;
+        w.rk_t0[cb] = (double)sg * tb[0];
+        w.rk_t1[cb] = (double)sg * tb[0];
+        w.out_idx[cb] = 1;
+        const int dn = (T < 2 || st != PHX_OK) ? 1 : 0;
+        w.done[cb] = dn;
+        w.accept[cb] = 0;
+        if (!dn && cfg.method == PHX_DOPRI5) atomicAdd(&w.sync->remaining, 1u);
+    }
+    for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+        const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+        if (n < d.N) {
+            const long long e = (long long)b * d.N + n;
+            const float v = y0[e];
+            w.Y0[e] = v;
+            sol[e] = v;
+        }
+    }
+    grid_barrier(gs, &s.flag);
+
+    if (cfg.method != PHX_DOPRI5) {
+        // ------------------------------------------------------------------ fixed grid
+        const int S = fixed_nstages(cfg.method);
+        for (int i = 0; i + 1 < T; ++i) {
+            for (int st = 0; st < S; ++st) {
+                for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+                    const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+                    const int cb = shared ? 0 : b;
+                    if (w.done[cb]) continue;
+                    const bool valid = n < d.N;
+                    const long long e = (long long)b * d.N + n;
+                    const double *tb = trow(t, d, cfg, b);
+                    const double sg = (double)w.sgn[cb];
+                    const double s0 = sg * tb[i], s1 = sg * tb[i + 1];
+                    const float dt = cfg.t_is_f32 ? ((float)s1 - (float)s0) : (float)(s1 - s0);
+                    float yv = 0.5f;
+                    if (valid) {
+                        yv = fixed_stage_input(cfg.method, st, w.Y0[e], w.KY, d.BN, e, dt);
+                        w.YS[e] = yv;
+                    }
+                    phaseA<false>(net, d, w, item, c, yv, 0.f, valid, false, -1, e, s);
+                }
+                grid_barrier(gs, &s.flag);
+                phaseB<false>(net, d, w, st, w.done, shared);
+                grid_barrier(gs, &s.flag);
+                for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+                    const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+                    const int cb = shared ? 0 : b;
+                    if (w.done[cb]) continue;
+                    const bool valid = n < d.N;
+                    const long long e = (long long)b * d.N + n;
+                    const float yv = valid ? w.YS[e] : 0.5f;
+                    float f, vjp, sgv;
+                    phaseC<false>(net, d, w, b, c, st, yv, 0.f, valid, false, f, vjp, sgv, s);
+                    if (valid) {
+                        w.KY[(long long)st * d.BN + e] = w.sgn[cb] * f;
+                        if (st == S - 1) {
+                            const double *tb = trow(t, d, cfg, b);
+                            const double sg = (double)w.sgn[cb];
+                            const double s0 = sg * tb[i], s1 = sg * tb[i + 1];
+                            const float dt = cfg.t_is_f32 ? ((float)s1 - (float)s0) : (float)(s1 - s0);
+                            const float y1 = fixed_final(cfg.method, w.Y0[e], w.KY, d.BN, e, dt);
+                            w.Y0[e] = y1;
+                            sol[(long long)(i + 1) * d.BN + e] = y1;
+                        }
+                    }
+                }
+            }
+        }
+        for (long long cb = gtid; cb < d.Bc; cb += gsize)
+            if (!w.done[cb]) { w.nsteps[cb] = T - 1; w.nfe[cb] = S * (T - 1); }
+    } else {
+        // ------------------------------------------------------------------ dopri5
+        // one RHS evaluation of every active trajectory: stage input -> K[kslot]
+        //   mode 0: input = Y0 (f0)       reductions d0,d1        (misc.py:62-67)
+        //   mode 1: input = Y0 + h0*K0    reductions d2           (misc.py:74-77)
+        //   mode 2: RK stage `st`         (st == 6: error-ratio reductions, misc.py:89-91)
+        auto eval = [&](int mode, int st, int kslot) {
+            for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+                const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+                const int cb = shared ? 0 : b;
+                if (w.done[cb]) continue;
+                const bool valid = n < d.N;
+                const long long e = (long long)b * d.N + n;
+                float yv = 0.5f;
+                if (valid) {
+                    if (mode == 0) yv = w.Y0[e];
+                    else if (mode == 1) yv = w.Y0[e] + w.h0f[cb] * w.KY[e];
+                    else yv = dp_stage_input(st, w.Y0[e], w.KY, d.BN, e, w.dtf[cb]);
+                    w.YS[e] = yv;
+                }
+                phaseA<false>(net, d, w, item, c, yv, 0.f, valid, false, -1, e, s);
+            }
+            grid_barrier(gs, &s.flag);
+            phaseB<false>(net, d, w, kslot, w.done, shared);
+            grid_barrier(gs, &s.flag);
+            for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+                const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+                const int cb = shared ? 0 : b;
+                if (w.done[cb]) continue;
+                const bool valid = n < d.N;
+                const long long e = (long long)b * d.N + n;
+                const float yv = valid ? w.YS[e] : 0.5f;
+                float f, vjp, sgv;
+                phaseC<false>(net, d, w, b, c, kslot, yv, 0.f, valid, false, f, vjp, sgv, s);
+                const float kv = w.sgn[cb] * f;
+                float r0 = 0.f, r1 = 0.f;
+                if (valid) {
+                    if (mode == 0) {
+                        w.KY[e] = kv;
+                        const float y0v = yv;
+                        const float scale = cfg.atol + fabsf(y0v) * cfg.rtol;
+                        const float q0 = y0v / scale, q1 = kv / scale;
+                        r0 = q0 * q0; r1 = q1 * q1;
+                    } else if (mode == 1) {
+                        const float y0v = w.Y0[e];
+                        const float scale = cfg.atol + fabsf(y0v) * cfg.rtol;
+                        const float q = (kv - w.KY[e]) / scale;
+                        r0 = q * q;
+                    } else {
+                        w.KY[(long long)kslot * d.BN + e] = kv;
+                        if (st == 6) {
+                            const float dt = w.dtf[cb];
+                            const float err = dp_combo(DP_CERR, w.KY, d.BN, e, dt);
+                            const float y0v = w.Y0[e];
+                            const float tol = cfg.atol + cfg.rtol * fmaxf(fabsf(y0v), fabsf(yv));
+                            const float q = err / tol;
+                            r0 = q * q;
+                        }
+                    }
+                }
+                if (mode != 2 || st == 6) {
+                    const float t0 = block_sum(r0, s.red);
+                    const float t1 = (mode == 0) ? block_sum(r1, s.red) : 0.f;
+                    if (tid == 0) { w.red[(long long)item * 4 + 0] = t0; w.red[(long long)item * 4 + 1] = t1; }
+                }
+            }
+        };
+        const double cnt = shared ? (double)d.BN : (double)d.N;
+
+        eval(0, 0, 0);
+        grid_barrier(gs, &s.flag);
+        for (long long cb = gtid; cb < d.Bc; cb += gsize) {
+            if (w.done[cb]) continue;
+            const float d0 = rms_from_sum(ctrl_sum(d, w, (int)cb, shared, 0), cnt);
+            const float d1 = rms_from_sum(ctrl_sum(d, w, (int)cb, shared, 1), cnt);
+            w.h0f[cb] = init_h0(d0, d1);
+            w.xfin[cb] = (double)d1;  // keep d1 for the second half
+        }
+        grid_barrier(gs, &s.flag);
+        eval(1, 0, 1);
+        grid_barrier(gs, &s.flag);
+        for (long long cb = gtid; cb < d.Bc; cb += gsize) {
+            if (w.done[cb]) continue;
+            const float h0 = w.h0f[cb];
+            const float d2 = rms_from_sum(ctrl_sum(d, w, (int)cb, shared, 0), cnt) / h0;
+            const double dt = init_dt(h0, (float)w.xfin[cb], d2);
+            w.dt[cb] = dt;
+            w.dtf[cb] = (float)dt;
+            w.nfe[cb] = 2;
+            const double t0 = w.rk_t1[cb];
+            if (!(t0 + dt > t0)) {  // rk_common.py:175
+                w.st[cb] = PHX_ERR_DT_UNDERFLOW;
+                w.done[cb] = 1;
+                atomicSub(&w.sync->remaining, 1u);
+            }
+        }
+        grid_barrier(gs, &s.flag);
+        if (tid == 0) s.remaining = __hip_atomic_load(&w.sync->remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        unsigned int remaining = s.remaining;
+
+        while (remaining > 0 && !gs.aborted) {
+            for (int st = 1; st <= 6; ++st) eval(2, st, st);
+            grid_barrier(gs, &s.flag);
+            // ---- controller: accept/reject, next dt, output scheduling (rk_common.py:150-220)
+            for (long long cb = gtid; cb < d.Bc; cb += gsize) {
+                if (w.done[cb]) continue;
+                const double *tb = trow(t, d, cfg, (int)cb);
+                const double sg = (double)w.sgn[cb];
+                const float ratio = rms_from_sum(ctrl_sum(d, w, (int)cb, shared, 0), cnt);
+                const int acc = (ratio <= 1.0f) ? 1 : 0;
+                const double t0 = w.rk_t1[cb], dt = w.dt[cb];
+                w.rk_t0[cb] = t0;
+                w.rk_t1[cb] = acc ? t0 + dt : t0;
+                w.accept[cb] = acc;
+                int ns = w.nsteps[cb] + 1;
+                w.nsteps[cb] = ns;
+                w.nfe[cb] += 6;
+                int oi = w.out_idx[cb];
+                w.out_lo[cb] = oi;
+                if (acc) {
+                    const double t1 = t0 + dt;
+                    while (oi < T && sg * tb[oi] <= t1) ++oi;
+                }
+                w.out_hi[cb] = oi;
+                w.out_idx[cb] = oi;
+                const double dtn = optimal_step_size(dt, ratio);
+                w.dtp[cb] = w.dtf[cb];
+                w.dt[cb] = dtn;
+                w.dtf[cb] = (float)dtn;
+                int dn = 0;
+                if (oi >= T) dn = 1;
+                else {
+                    const double tn = w.rk_t1[cb];
+                    if (!(tn + dtn > tn)) { w.st[cb] = PHX_ERR_DT_UNDERFLOW; dn = 1; }
+                    else if ((long long)ns >= cfg.max_steps) { w.st[cb] = PHX_ERR_MAX_STEPS; dn = 1; }
+                }
+                if (dn) {
+                    w.fin[cb] = 1;  // finish after this step's accept pass
+                    atomicSub(&w.sync->remaining, 1u);
+                } else w.fin[cb] = 0;
+            }
+            grid_barrier(gs, &s.flag);
+            if (tid == 0) s.remaining = __hip_atomic_load(&w.sync->remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            remaining = s.remaining;
+            // ---- accept pass: dense output at the requested times, advance the state (FSAL)
+            for (int item = blockIdx.x; item < d.items; item += gridDim.x) {
+                const int b = item / d.NC, c = item % d.NC, n = c * CH + tid;
+                const int cb = shared ? 0 : b;
+                if (w.done[cb] || !w.accept[cb]) continue;
+                if (n >= d.N) continue;
+                const long long e = (long long)b * d.N + n;
+                const float y0v = w.Y0[e], y1v = w.YS[e];
+                const float f0 = w.KY[e], f1 = w.KY[6 * d.BN + e];
+                const int lo = w.out_lo[cb], hi = w.out_hi[cb];
+                if (hi > lo) {
+                    // _interp_fit gets the fp32 cast of the dt of the step just taken (rk_common.py:224)
+                    const double t0 = w.rk_t0[cb], t1 = w.rk_t1[cb];
+                    const float dts = w.dtp[cb];
+                    const float ym = y0v + dp_combo(DP_CMID, w.KY, d.BN, e, dts);
+                    const double *tb = trow(t, d, cfg, b);
+                    const double sg = (double)w.sgn[cb];
+                    for (int jo = lo; jo < hi; ++jo) {
+                        const double x = (sg * tb[jo] - t0) / (t1 - t0);
+                        const InterpX ix = make_interp_x(x);
+                        sol[(long long)jo * d.BN + e] = interp_eval(y0v, y1v, ym, f0, f1, dts, ix);
+                    }
+                }
+                w.Y0[e] = y1v;
+                w.KY[e] = f1;
+            }
+            // controllers flagged `fin` retire now (their items were still needed by the accept pass)
+            grid_barrier(gs, &s.flag);
+            for (long long cb = gtid; cb < d.Bc; cb += gsize)
+                if (!w.done[cb] && w.fin[cb]) w.done[cb] = 1;
+            grid_barrier(gs, &s.flag);
+        }
+    }
+    // ---- results
+    grid_barrier(gs, &s.flag);
+    for (long long b = gtid; b < d.B; b += gsize) {
+        const int cb = shared ? 0 : (int)b;
+        int st = w.st[cb];
+        if (gs.aborted) st = PHX_ERR_SYNC_TIMEOUT;
+        status[b] = st;
+        nfe[b] = w.nfe[cb];
+        nsteps[b] = w.nsteps[cb];
+    }
+}
+
+}  // namespace
+
+// ========================================================================================
+// adjoint solve lives in its own translation unit section below
+// ========================================================================================
+#include "phx_adjoint.inc"
+
+// ========================================================================================
+// host side: C ABI
+// ========================================================================================
+namespace {
+
+int g_num_cus = -1;
+int num_cus()
+{
+    if (g_num_cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        g_num_cus = n;
+    }
+    return g_num_cus;
+}
+
+inline Net to_net(const phx_params *p) { return Net{p->Ws, p->bs, p->Wp, p->bp, p->WaT, p->g, p->N, p->H}; }
+
+inline bool bad_params(const phx_params *p)
+{
+    return !p || p->N <= 0 || p->H <= 0 || p->H > CH / 2 /* hidden vector staged in one LDS chunk */ || !p->Ws || !p->bs || !p->Wp || !p->bp || !p->WaT || !p->g;
+}
+
+inline int grid_for(int work_items)
+{
+    const int cus = num_cus();
+    if (cus <= 0) return 0;
+    return std::max(1, std::min(cus, work_items));
+}
+
+inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStream_t st)
+{
+    const long long total = 4LL * d.H * d.N + d.N + 2 * d.H;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w.dtheta, d.GB, d.PP, d.N, d.H, g->Ws, g->Wp,
+                       g->WaT, g->g, g->bs, g->bp);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phx_abi_version(void) { return PHX_ABI_VERSION; }
+
+const char *phx_status_string(int s)
+{
+    switch (s) {
+        case PHX_OK: return "ok";
+        case PHX_ERR_MAX_STEPS: return "max_num_steps exceeded";
+        case PHX_ERR_DT_UNDERFLOW: return "underflow in dt";
+        case PHX_ERR_NONFINITE: return "non-finite values in state `y`";
+        case PHX_ERR_BAD_ARG: return "bad argument";
+        case PHX_ERR_WORKSPACE: return "workspace too small";
+        case PHX_ERR_LAUNCH: return "HIP launch failure";
+        case PHX_ERR_SYNC_TIMEOUT: return "in-kernel grid barrier timed out";
+        default: return "unknown status";
+    }
+}
+
+int phx_device_cus(void) { return num_cus(); }
+
+size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
+{
+    if (N <= 0 || H <= 0 || B <= 0 || T < 0) return 0;
+    const Dims d = make_dims(N, H, B, T, PHX_CTRL_PER_TRAJECTORY);
+    return make_layout(d, op).total;
+}
+
+int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int prior_only, void *workspace,
+                    size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !y || !out || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);
+    const Layout L = make_layout(d, PHX_OP_RHS_FORWARD);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_eval<false>, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, y, (const float *)nullptr, out,
+                       (float *)nullptr, prior_only, 0, (int *)nullptr);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vjp_y, const phx_grads *grads,
+                float *f_out, int B, int prior_only, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !y || !cot || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
+        return PHX_ERR_BAD_ARG;
+    const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);
+    const Layout L = make_layout(d, PHX_OP_RHS_VJP);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
+    if (grads && hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess)
+        return PHX_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_eval<true>, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, y, cot, f_out, vjp_y, prior_only,
+                       grads ? 1 : 0, (int *)nullptr);
+    if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+    if (grads) return launch_reduce(d, w, grads, st);
+    return PHX_OK;
+}
+
+int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int T, const phx_solve_opts *o,
+               float *sol, int *status, int *nfe, int *nsteps, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !y0 || !t || !o || !sol || !status || !nfe || !nsteps || B <= 0 || T < 1 || !workspace)
+        return PHX_ERR_BAD_ARG;
+    if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
+    if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
+    const Dims d = make_dims(p->N, p->H, B, T, o->control);
+    const Layout L = make_layout(d, PHX_OP_ODEINT);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
+    SolveCfg cfg;
+    cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
+    cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
+    cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_solve_fwd, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, y0, t, sol, status, nfe,
+                       nsteps);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int T, const phx_solve_opts *o,
+                                const float *y_saved, const float *grad_y, float *adj_y0, const phx_grads *grads,
+                                int *status, int *nfe, int *nsteps, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    if (bad_params(p) || !t || !o || !y_saved || !grad_y || !adj_y0 || !status || !nfe || !nsteps || B <= 0 ||
+        T < 1 || !workspace)
+        return PHX_ERR_BAD_ARG;
+    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
+        return PHX_ERR_BAD_ARG;
+    if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
+    if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
+    const Dims d = make_dims(p->N, p->H, B, T, o->control);
+    const Layout L = make_layout(d, PHX_OP_ADJOINT);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
+    SolveCfg cfg;
+    cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
+    cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
+    cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
+    if (hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess) return PHX_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_solve_adj, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, t, y_saved, grad_y, adj_y0,
+                       status, nfe, nsteps, grads ? 1 : 0);
+    if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+    if (grads) return launch_reduce(d, w, grads, st);
+    return PHX_OK;
+}
+
+}  // extern "C"

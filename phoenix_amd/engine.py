@@ -1,0 +1,145 @@
+"""Thin torch <-> C-ABI glue: device pointers, the current HIP stream, caller-owned workspaces.
+
+PyTorch here is plumbing (device memory, streams, autograd bookkeeping); all arithmetic of the
+path happens in libphoenix_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_ws_cache = {}
+
+
+def _require_gpu(x, name):
+    if not x.is_cuda:
+        raise RuntimeError("phoenix_amd: `%s` must live on the GPU (cuda/HIP device); this engine has no CPU path"
+                           % name)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(op, N, H, B, T, device):
+    nbytes = _lib.load().phx_workspace_bytes(op, N, H, B, T)
+    key = (device.index, torch.cuda.current_stream().cuda_stream, op)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf, nbytes
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Params:
+    """Device-side view of ODENet parameters in the engine layout (include/phoenix_hip.h)."""
+
+    def __init__(self, Ws, bs, Wp, bp, Wa, g):
+        for n, x in (("Ws", Ws), ("bs", bs), ("Wp", Wp), ("bp", bp), ("Wa", Wa), ("g", g)):
+            _require_gpu(x, n)
+            if x.dtype != torch.float32:
+                raise TypeError("phoenix_amd: parameter %s must be float32 (got %s)" % (n, x.dtype))
+        self.H, self.N = Ws.shape
+        assert Wp.shape == (self.H, self.N) and Wa.shape == (self.N, 2 * self.H), "not a PHOENIX ODENet"
+        self.Ws = Ws.detach().contiguous()
+        self.bs = bs.detach().contiguous()
+        self.Wp = Wp.detach().contiguous()
+        self.bp = bp.detach().contiguous()
+        self.WaT = Wa.detach().t().contiguous()   # gene-contiguous [2H, N]
+        self.g = g.detach().reshape(-1).contiguous()
+        self.device = Ws.device
+        self.c = _lib.PhxParams(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g),
+                                self.N, self.H)
+
+    def new_grads(self):
+        return Grads(self)
+
+
+class Grads:
+    def __init__(self, p):
+        z = lambda x: torch.zeros_like(x)
+        self.Ws, self.bs, self.Wp, self.bp, self.WaT, self.g = z(p.Ws), z(p.bs), z(p.Wp), z(p.bp), z(p.WaT), z(p.g)
+        self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g))
+
+    def as_reference_layout(self, g_shape):
+        """(Ws, bs, Wp, bp, Wa[N,2H], g[1,N]) gradients in the reference's parameter layouts"""
+        return self.Ws, self.bs, self.Wp, self.bp, self.WaT.t(), self.g.reshape(g_shape)
+
+
+def _check_call(rc):
+    if rc != 0:
+        raise RuntimeError("phoenix_amd: %s" % _lib.load().phx_status_string(rc).decode())
+
+
+def raise_for_status(status):
+    """Maps per-trajectory solver status onto the reference's exceptions (rk_common.py:154,175-176,
+    misc.py:114-115).  One device->host read."""
+    worst = int(status.max().item())
+    if worst == 0:
+        return
+    bad = int((status != 0).nonzero()[0].item())
+    msg = "%s (trajectory %d)" % (_lib.STATUS_TEXT.get(worst, "status %d" % worst), bad)
+    if worst in (1, 2, 3, 4):
+        raise AssertionError(msg)
+    raise RuntimeError("phoenix_amd: " + msg)
+
+
+def rhs_forward(p, y, prior_only=False):
+    _require_gpu(y, "y")
+    y2 = y.detach().reshape(-1, p.N).contiguous()
+    out = torch.empty_like(y2)
+    B = y2.shape[0]
+    ws, nb = _workspace(_lib.OP_RHS_FORWARD, p.N, p.H, B, 0, y.device)
+    _check_call(_lib.load().phx_rhs_forward(C.byref(p.c), _p(y2), _p(out), B, int(prior_only), _p(ws), nb,
+                                            _stream_ptr()))
+    return out.reshape(y.shape)
+
+
+def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True):
+    _require_gpu(y, "y")
+    y2 = y.detach().reshape(-1, p.N).contiguous()
+    c2 = cot.detach().reshape(-1, p.N).contiguous()
+    B = y2.shape[0]
+    vjp = torch.empty_like(y2) if want_vjp_y else None
+    grads = p.new_grads() if want_grads else None
+    ws, nb = _workspace(_lib.OP_RHS_VJP, p.N, p.H, B, 0, y.device)
+    _check_call(_lib.load().phx_rhs_vjp(C.byref(p.c), _p(y2), _p(c2), _p(vjp), C.byref(grads.c) if grads else None,
+                                        C.c_void_p(0), B, int(prior_only), _p(ws), nb, _stream_ptr()))
+    return (vjp.reshape(y.shape) if want_vjp_y else None), grads
+
+
+def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps):
+    return _lib.PhxSolveOpts(_lib.METHODS[method], control, float(rtol), float(atol), int(t_per_sample),
+                             int(t_is_f32), int(max_num_steps))
+
+
+def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0):
+    """y0 [B,N] f32, t64 [T] or [B,T] f64 (device) -> sol [T,B,N], status[B], nfe[B], nsteps[B]"""
+    B, N = y0.shape
+    T = t64.shape[-1]
+    sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
+    stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
+    ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device)
+    o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)
+    _check_call(_lib.load().phx_odeint(C.byref(p.c), _p(y0), _p(t64), B, T, C.byref(o), _p(sol), _p(stats[0]),
+                                       _p(stats[1]), _p(stats[2]), _p(ws), nb, _stream_ptr()))
+    return sol, stats[0], stats[1], stats[2]
+
+
+def solve_adjoint(p, t64, y_saved, grad_y, method, control, rtol, atol, t_per_sample, t_is_f32, want_grads=True,
+                  max_num_steps=0):
+    """y_saved, grad_y [T,B,N] -> adj_y0 [B,N], Grads, status, nfe, nsteps"""
+    T, B, N = y_saved.shape
+    adj = torch.empty((B, N), dtype=torch.float32, device=y_saved.device)
+    stats = torch.zeros((3, B), dtype=torch.int32, device=y_saved.device)
+    grads = p.new_grads() if want_grads else None
+    ws, nb = _workspace(_lib.OP_ADJOINT, p.N, p.H, B, T, y_saved.device)
+    o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)
+    _check_call(_lib.load().phx_odeint_adjoint_backward(
+        C.byref(p.c), _p(t64), B, T, C.byref(o), _p(y_saved), _p(grad_y), _p(adj),
+        C.byref(grads.c) if grads else None, _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(ws), nb, _stream_ptr()))
+    return adj, grads, stats[0], stats[1], stats[2]

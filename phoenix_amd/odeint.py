@@ -1,0 +1,167 @@
+"""Drop-in `odeint` / `odeint_adjoint` for PHOENIX's ODENet on MI355X.
+
+Mirrors the reference surface (vendored torchdiffeq 0.1.1):
+    odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None)          _impl/odeint.py:30
+    odeint_adjoint(func, y0, t, rtol, atol, method, options, adjoint_rtol, adjoint_atol,
+                   adjoint_method, adjoint_options, adjoint_params)                 _impl/adjoint.py:165
+Same argument meaning, output shape `[len(t), *y0.shape]`, default method 'dopri5', the same
+exceptions (ValueError for an unknown method, AssertionError for the solver asserts).
+
+Extension (what the reference's training loop *means*, train_insilico.py:128-130): `t` may be 2-D
+`[B, T]` -- one time grid per sample of `y0 [B, 1, N]` -- which integrates all B samples in ONE launch
+with an independent step controller per sample (`odeint_per_sample` is the explicit spelling)."""
+import warnings
+
+import torch
+
+from . import _lib, engine
+from .odenet import params_of
+
+# torchdiffeq's registry (odeint.py:14-27); the engine implements the ones PHOENIX's configs use.
+SOLVERS = ("dopri8", "dopri5", "bosh3", "adaptive_heun", "euler", "midpoint", "rk4", "explicit_adams",
+           "implicit_adams", "fixed_adams")
+_ENGINE_METHODS = ("dopri5", "euler", "midpoint", "rk4")
+_KNOWN_UNSUPPORTED_OPTIONS = ("step_size", "grid_constructor", "grid_points", "eps", "first_step", "safety",
+                              "ifactor", "dfactor", "norm", "dtype")
+
+
+def _check_inputs(func, y0, t, rtol, atol, method, options):
+    """misc.py:165-241, restricted to what the engine supports."""
+    if not torch.is_tensor(y0):
+        raise NotImplementedError("phoenix_amd: tuple states are not supported (PHOENIX passes a single tensor)")
+    if not torch.is_floating_point(y0):
+        raise TypeError("`y0` must be a floating point Tensor but is a {}".format(y0.type()))
+    if y0.dtype != torch.float32:
+        raise NotImplementedError("phoenix_amd: the engine computes in float32 like the reference's configs; "
+                                  "got y0 dtype %s" % y0.dtype)
+    options = {} if options is None else dict(options)
+    if method is None:
+        method = "dopri5"
+    if method not in SOLVERS:
+        raise ValueError('Invalid method "{}". Must be one of {}'.format(
+            method, '{"' + '", "'.join(SOLVERS) + '"}.'))
+    if method not in _ENGINE_METHODS:
+        raise NotImplementedError("phoenix_amd: method '%s' is registered in torchdiffeq but not on PHOENIX's "
+                                  "path (configs use dopri5; rk4/euler/midpoint are implemented)" % method)
+    assert torch.is_tensor(t), "t must be a torch.Tensor"
+    assert t.ndimension() in (1, 2), "t must be one dimensional"
+    if not torch.is_floating_point(t):
+        raise TypeError("`t` must be a floating point Tensor but is a {}".format(t.type()))
+    for k in list(options):
+        if k in _KNOWN_UNSUPPORTED_OPTIONS:
+            raise NotImplementedError("phoenix_amd: solver option '%s' is not supported by the fused stepper" % k)
+        if k not in ("max_num_steps", "batch_control"):
+            warnings.warn("phoenix_amd: Unexpected arguments {}".format({k: options.pop(k)}))
+    if torch.is_tensor(rtol) or torch.is_tensor(atol):
+        rtol, atol = float(rtol), float(atol)
+    return y0, t, float(rtol), float(atol), method, options
+
+
+def _prepare(func, y0, t, options):
+    ws, bs, wp, bp, wa, g = params_of(func)
+    N = ws.shape[1]
+    if y0.shape[-1] != N:
+        raise ValueError("phoenix_amd: y0 last dimension %d != number of genes %d" % (y0.shape[-1], N))
+    engine._require_gpu(y0, "y0")
+    y2 = y0.reshape(-1, N)
+    B = y2.shape[0]
+    t_is_f32 = t.dtype == torch.float32
+    if t.device != y0.device:
+        warnings.warn("t is not on the same device as y0. Coercing to y0.device.")   # misc.py:232-235
+    t64 = t.detach().to(device=y0.device, dtype=torch.float64).contiguous()
+    per_sample = t.ndimension() == 2
+    if per_sample and t.shape[0] != B:
+        raise ValueError("phoenix_amd: per-sample t must be [B, T] with B = %d trajectories" % B)
+    ctl = options.get("batch_control", "per_trajectory" if per_sample else "shared")
+    if ctl not in ("shared", "per_trajectory"):
+        raise ValueError("batch_control must be 'shared' or 'per_trajectory'")
+    if per_sample and ctl == "shared":
+        raise ValueError("per-sample time grids need batch_control='per_trajectory'")
+    control = _lib.CTRL_SHARED if ctl == "shared" else _lib.CTRL_PER_TRAJECTORY
+    return (ws, bs, wp, bp, wa, g), y2, t64, B, N, per_sample, t_is_f32, control
+
+
+def _out_shape(sol, y0, per_sample):
+    # [T, B, N] -> [T, *y0.shape]
+    return sol.reshape((sol.shape[0],) + tuple(y0.shape))
+
+
+class _OdeintAdjointFn(torch.autograd.Function):
+    """OdeintAdjointMethod (adjoint.py:9-162): forward = no-grad solve, saves (t, y, params);
+    backward = reverse-time augmented solve on the engine."""
+
+    @staticmethod
+    def forward(ctx, y2, t64, cfg, ws, bs, wp, bp, wa, g):
+        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj) = cfg
+        p = engine.Params(ws, bs, wp, bp, wa, g)
+        sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol,
+                                                        atol, per_sample, t_is_f32, max_steps)
+        engine.raise_for_status(status)
+        ctx.cfg = cfg
+        ctx.save_for_backward(t64, sol, ws, bs, wp, bp, wa, g)
+        ctx.mark_non_differentiable(nfe)
+        return sol, nfe
+
+    @staticmethod
+    def backward(ctx, grad_sol, _grad_nfe):
+        t64, sol, ws, bs, wp, bp, wa, g = ctx.saved_tensors
+        if grad_sol is None:
+            grad_sol = torch.zeros_like(sol)
+        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj) = ctx.cfg
+        a_method, a_rtol, a_atol = adj
+        p = engine.Params(ws, bs, wp, bp, wa, g)
+        need_p = any(ctx.needs_input_grad[3:])
+        adj_y0, grads, status, _nfe, _ns = engine.solve_adjoint(
+            p, t64, sol, grad_sol.contiguous(), a_method, control, a_rtol, a_atol, per_sample, t_is_f32,
+            want_grads=need_p, max_num_steps=max_steps)
+        engine.raise_for_status(status)
+        if need_p:
+            gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)
+        else:
+            gws = gbs = gwp = gbp = gwa = gg = None
+        return adj_y0, None, None, gws, gbs, gwp, gbp, gwa, gg
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_stats=False):
+    """Forward solve only (odeint.py:30-74).  The result carries no autograd history: the reference's
+    training/validation code always differentiates through `odeint_adjoint` (train_insilico.py:15-18)."""
+    y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
+    params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
+    p = engine.Params(*params)
+    sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol, atol,
+                                                    per_sample, t_is_f32, int(options.get("max_num_steps", 0)))
+    engine.raise_for_status(status)
+    out = _out_shape(sol, y0, per_sample)
+    return (out, nfe, nsteps) if return_stats else out
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None,
+                   adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
+    """adjoint.py:165-204.  Gradients flow to y0 and to the six ODENet parameters."""
+    if adjoint_params is not None:
+        raise NotImplementedError("phoenix_amd: adjoint_params is fixed to ODENet's six parameters")
+    if adjoint_options:
+        raise NotImplementedError("phoenix_amd: adjoint_options are not supported by the fused stepper")
+    if adjoint_rtol is None:
+        adjoint_rtol = rtol
+    if adjoint_atol is None:
+        adjoint_atol = atol
+    y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
+    if adjoint_method is None:
+        adjoint_method = method
+    if adjoint_method not in _ENGINE_METHODS:
+        raise NotImplementedError("phoenix_amd: adjoint_method '%s' not supported" % adjoint_method)
+    params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
+    cfg = (method, control, rtol, atol, per_sample, t_is_f32, int(options.get("max_num_steps", 0)),
+           (adjoint_method, float(adjoint_rtol), float(adjoint_atol)))
+    sol, _nfe = _OdeintAdjointFn.apply(y2, t64, cfg, *params)
+    return _out_shape(sol, y0, per_sample)
+
+
+def odeint_per_sample(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint=True):
+    """The reference's per-sample python loop as ONE launch:
+        for time, batch_point in zip(t, batch): odeint(odenet, batch_point, time, method)[1]
+    y0 [B,1,N] (or [B,N]), t [B,T]; returns [T, *y0.shape]; independent step control per sample."""
+    assert t.ndimension() == 2, "odeint_per_sample needs t of shape [B, T]"
+    fn = odeint_adjoint if adjoint else odeint
+    return fn(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)

@@ -1,0 +1,82 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol that
+include/phoenix_hip.h declares; host-side argument logic mirrors the reference's errors."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "phoenix_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(phx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from phoenix_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.phx_abi_version() == 1
+    assert lib.phx_status_string(2).decode() == "underflow in dt"
+
+
+def test_workspace_bytes_monotone_and_positive():
+    from phoenix_amd import _lib
+    lib = _lib.load()
+    a = lib.phx_workspace_bytes(_lib.OP_ODEINT, 350, 40, 64, 5)
+    b = lib.phx_workspace_bytes(_lib.OP_ODEINT, 350, 40, 1024, 5)
+    c = lib.phx_workspace_bytes(_lib.OP_ADJOINT, 350, 40, 1024, 5)
+    assert 0 < a < b < c
+    assert lib.phx_workspace_bytes(_lib.OP_RHS_FORWARD, 0, 40, 1, 0) == 0
+
+
+def test_null_arguments_are_rejected_without_a_gpu():
+    from phoenix_amd import _lib
+    lib = _lib.load()
+    assert lib.phx_rhs_forward(None, None, None, 1, 0, None, 0, None) == 4  # PHX_ERR_BAD_ARG
+
+
+def test_no_cpu_fallback():
+    import phoenix_amd
+    net = phoenix_amd.ODENet("cpu", 16, neurons=4)
+    y0 = torch.rand(1, 16)
+    with pytest.raises(RuntimeError, match="no CPU path|must live on the GPU"):
+        phoenix_amd.odeint(net, y0, torch.tensor([0.0, 1.0]))
+    with pytest.raises(RuntimeError, match="no CPU path|must live on the GPU"):
+        net(torch.tensor(0.0), y0)
+
+
+def test_argument_errors_match_reference():
+    import phoenix_amd
+    net = phoenix_amd.ODENet("cpu", 16, neurons=4)
+    y0 = torch.rand(1, 16)
+    t = torch.tensor([0.0, 1.0])
+    with pytest.raises(ValueError, match='Invalid method "foo"'):        # misc.py:184-186
+        phoenix_amd.odeint(net, y0, t, method="foo")
+    with pytest.raises(TypeError, match="`t` must be a floating point"):   # misc.py:118-120
+        phoenix_amd.odeint(net, y0, torch.tensor([0, 1]))
+    with pytest.raises(TypeError, match="`y0` must be a floating point"):
+        phoenix_amd.odeint(net, torch.zeros(1, 16, dtype=torch.int64), t)
+    with pytest.raises(NotImplementedError):
+        phoenix_amd.odeint(net, y0, t, method="bosh3")
+    with pytest.raises(TypeError, match="ODENet only"):
+        phoenix_amd.odeint(torch.nn.Linear(16, 16), y0, t)
+
+
+def test_odenet_mirror_has_reference_structure():
+    import phoenix_amd
+    net = phoenix_amd.ODENet("cpu", 30, neurons=5)
+    names = [n for n, _ in net.named_parameters()]
+    # parameters() order of the reference
+    assert names == ["gene_multipliers", "net_prods.linear_out.weight", "net_prods.linear_out.bias",
+                     "net_sums.linear_out.weight", "net_sums.linear_out.bias", "net_alpha_combine.linear_out.weight"]
+    assert net.net_alpha_combine.linear_out.weight.shape == (30, 10)
+    assert net.gene_multipliers.shape == (1, 30)
+    w = net.net_sums.linear_out.weight
+    assert (w == 0).float().mean() >= 0.9   # nn.init.sparse_(sparsity=0.95)

@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP engine (through the C ABI, via phoenix_amd) against
+  (1) the golden vectors captured from the reference, and
+  (2) the CPU oracle on fresh seeded inputs at larger sizes,
+plus size-independent properties at BASELINE.json's full sizes.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, net_from, relerr, sub
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("Ws", "bs", "Wp", "bp", "Wa", "g")
+TOL_RHS = 5e-6        # fp32 sums in a different order (tree/shuffle vs MKL)
+TOL_FIXED = 1e-5      # north_star tolerance on trajectories
+TOL_DOPRI = 1e-5
+TOL_DOPRI_GRAD = 5e-5  # see tests/test_oracle_vs_golden.py: adaptive fp32 noise floor of the gradients
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import phoenix_amd
+    return phoenix_amd
+
+
+def make_net(pa, dev, p):
+    """phoenix_amd.ODENet carrying the given parameter arrays (reference layouts)"""
+    H, N = p["Ws"].shape
+    net = pa.ODENet(dev, N, neurons=H)
+    with torch.no_grad():
+        net.net_sums.linear_out.weight.copy_(torch.from_numpy(p["Ws"]))
+        net.net_sums.linear_out.bias.copy_(torch.from_numpy(p["bs"]))
+        net.net_prods.linear_out.weight.copy_(torch.from_numpy(p["Wp"]))
+        net.net_prods.linear_out.bias.copy_(torch.from_numpy(p["bp"]))
+        net.net_alpha_combine.linear_out.weight.copy_(torch.from_numpy(p["Wa"]))
+        net.gene_multipliers.copy_(torch.from_numpy(p["g"]).reshape(1, N))
+    return net
+
+
+def grads_of(net):
+    def g(p):
+        return (torch.zeros_like(p) if p.grad is None else p.grad).detach().cpu().numpy()
+    return {"Ws": g(net.net_sums.linear_out.weight), "bs": g(net.net_sums.linear_out.bias),
+            "Wp": g(net.net_prods.linear_out.weight), "bp": g(net.net_prods.linear_out.bias),
+            "Wa": g(net.net_alpha_combine.linear_out.weight), "g": g(net.gene_multipliers).reshape(-1)}
+
+
+def zero_grads(net):
+    for p in net.parameters():
+        p.grad = None
+
+
+def rand_params(N, H, seed, std=0.1, neg=0.1):
+    r = np.random.RandomState(seed)
+    g = r.rand(N).astype(np.float32)
+    g[r.rand(N) < neg] *= -1
+    return {"Ws": (r.randn(H, N) * std).astype(np.float32), "bs": r.uniform(-.2, .2, H).astype(np.float32),
+            "Wp": (r.randn(H, N) * std).astype(np.float32), "bp": r.uniform(-.2, .2, H).astype(np.float32),
+            "Wa": (r.randn(N, 2 * H) * std).astype(np.float32), "g": g}
+
+
+def onet_of(oracle, p):
+    return oracle.Net(p["Ws"], p["bs"], p["Wp"], p["bp"], p["Wa"], p["g"])
+
+
+# --------------------------------------------------------------------------- goldens
+@pytest.mark.parametrize("case", ["sparse", "dense", "odd"])
+def test_g1_g2_rhs_and_vjp(pa, dev, case):
+    g = sub(load_golden("g1_g2_rhs"), case + "/")
+    net = make_net(pa, dev, sub(g, "p_"))
+    y = torch.from_numpy(g["y"]).to(dev)
+    t0 = torch.tensor(0.0, device=dev)
+    assert relerr(net(t0, y).detach().cpu().numpy(), g["f"]) < TOL_RHS
+    assert relerr(net.prior_only_forward(t0, y).detach().cpu().numpy(), g["f_prior"]) < TOL_RHS
+    assert relerr(net(t0, torch.from_numpy(g["y1"]).to(dev)).detach().cpu().numpy(), g["f1"]) < TOL_RHS
+    cot = torch.from_numpy(g["cot"]).to(dev)
+    for prior, pre, fy in ((False, "vjp_", "vjp_y"), (True, "vjpprior_", "vjp_y_prior")):
+        zero_grads(net)
+        yv = y.clone().requires_grad_(True)
+        out = net.prior_only_forward(t0, yv) if prior else net(t0, yv)
+        out.backward(cot)
+        assert relerr(yv.grad.cpu().numpy(), g[fy]) < TOL_RHS
+        got = grads_of(net)
+        for k in KEYS:
+            ref = g[pre + k]
+            if np.max(np.abs(ref)) == 0:
+                assert np.max(np.abs(got[k])) == 0, k
+            else:
+                assert relerr(got[k], ref) < TOL_RHS, (k, prior)
+
+
+@pytest.mark.parametrize("method", ["euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("tname", ["t2", "t5", "t5_64", "t_dec"])
+@pytest.mark.parametrize("yname", ["single", "batch"])
+def test_g3_fixed(pa, dev, method, tname, yname):
+    g = load_golden("g3_fixed")
+    net = make_net(pa, dev, sub(g, "p_"))
+    c = sub(g, "%s/%s/%s/" % (method, tname, yname))
+    y0 = torch.from_numpy(g["y0_" + yname]).to(dev)
+    t = torch.from_numpy(g[tname]).to(dev)
+    sol = pa.odeint(net, y0, t, method=method)
+    assert sol.shape == c["sol"].shape
+    assert relerr(sol.cpu().numpy(), c["sol"]) < TOL_FIXED
+    if "G" in c:
+        zero_grads(net)
+        y0r = y0.clone().requires_grad_(True)
+        s2 = pa.odeint_adjoint(net, y0r, t, method=method)
+        (s2 * torch.from_numpy(c["G"]).to(dev)).sum().backward()
+        assert relerr(y0r.grad.cpu().numpy(), c["grad_y0"]) < TOL_FIXED
+        got = grads_of(net)
+        for k in KEYS:
+            assert relerr(got[k], c["grad_" + k]) < TOL_FIXED, k
+
+
+@pytest.mark.parametrize("tname", ["t2", "t4", "t10_64", "t_dec"])
+@pytest.mark.parametrize("yname", ["single", "batch"])
+def test_g4_dopri5(pa, dev, tname, yname):
+    g = load_golden("g4_dopri5")
+    net = make_net(pa, dev, sub(g, "p_"))
+    c = sub(g, "%s/%s/" % (tname, yname))
+    y0 = torch.from_numpy(g["y0_" + yname]).to(dev)
+    t = torch.from_numpy(g[tname]).to(dev)
+    sol = pa.odeint(net, y0, t)   # default dopri5 / 1e-7 / 1e-9; shared step control like the reference
+    assert relerr(sol.cpu().numpy(), c["sol"]) < TOL_DOPRI
+    assert relerr(sol.cpu().numpy(), c["truth64"]) < TOL_DOPRI
+    if "G" in c:
+        zero_grads(net)
+        y0r = y0.clone().requires_grad_(True)
+        s2 = pa.odeint_adjoint(net, y0r, t)
+        (s2 * torch.from_numpy(c["G"]).to(dev)).sum().backward()
+        assert relerr(y0r.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+        got = grads_of(net)
+        for k in KEYS:
+            assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+
+
+def test_g4_per_sample_loop_as_one_launch(pa, dev):
+    g = load_golden("g4_dopri5")
+    net = make_net(pa, dev, sub(g, "p_"))
+    c = sub(g, "loop/")
+    y0 = torch.from_numpy(g["y0_batch"]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(c["t"]).to(dev)
+    pred = pa.odeint_adjoint(net, y0, t)[1]
+    assert relerr(pred.detach().cpu().numpy(), c["pred"]) < TOL_DOPRI
+    (pred * torch.from_numpy(c["G"]).to(dev)).sum().backward()
+    assert relerr(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+    got = grads_of(net)
+    for k in KEYS:
+        assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+
+
+class _Handler:
+    def __init__(self, b, t, y):
+        self.b = (b, t, y)
+        self.device = b.device
+
+    def get_batch(self, bs):
+        return self.b
+
+
+@pytest.mark.parametrize("method", ["dopri5", "rk4"])
+@pytest.mark.parametrize("lam", [0.99, 1.0])
+def test_g5_training_step(pa, dev, method, lam):
+    g = sub(load_golden("g5_training_step"), "%s/lam%g/" % (method, lam))
+    net = make_net(pa, dev, sub(g, "p_"))
+    lr = float(g["lr"])
+    opt = torch.optim.Adam([
+        {"params": net.net_sums.linear_out.weight}, {"params": net.net_sums.linear_out.bias},
+        {"params": net.net_prods.linear_out.weight}, {"params": net.net_prods.linear_out.bias},
+        {"params": net.net_alpha_combine.linear_out.weight},
+        {"params": net.gene_multipliers, "lr": 5 * lr}], lr=lr, weight_decay=0)
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    h = _Handler(T("batch"), T("t"), T("target"))
+    with torch.no_grad():
+        pred = pa.odeint(net, h.b[0], h.b[1], method=method)[1]
+    tol = TOL_DOPRI if method == "dopri5" else TOL_FIXED
+    gtol = TOL_DOPRI_GRAD if method == "dopri5" else TOL_FIXED
+    assert relerr(pred.cpu().numpy(), g["pred"]) < tol
+    loss_data, loss_prior = pa.training_step(net, h, opt, method, 4, False, False, T("X"), T("prior_grad"), lam)
+    assert abs(loss_data.item() - float(g["loss_data"])) < 1e-5 * abs(float(g["loss_data"]))
+    assert abs(loss_prior.item() - float(g["loss_prior"])) < 1e-5 * abs(float(g["loss_prior"]))
+    got = grads_of(net)
+    for k in KEYS:
+        assert relerr(got[k], g["grad_" + k]) < gtol, k
+    after = {"Ws": net.net_sums.linear_out.weight, "bs": net.net_sums.linear_out.bias,
+             "Wp": net.net_prods.linear_out.weight, "bp": net.net_prods.linear_out.bias,
+             "Wa": net.net_alpha_combine.linear_out.weight, "g": net.gene_multipliers.reshape(-1)}
+    for k in KEYS:
+        # Adam's first step moves every touched weight by +-lr regardless of gradient size: compare directly
+        assert np.max(np.abs(after[k].detach().cpu().numpy() - g["after_" + k])) < 2.1 * lr * 5, k
+        big = np.abs(g["grad_" + k]) > 1e-3 * np.abs(g["grad_" + k]).max()
+        d = np.abs(after[k].detach().cpu().numpy() - g["after_" + k])[big]
+        assert d.size == 0 or d.max() < 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["yeast", "breast"])
+def test_g7_realdata(pa, dev, name):
+    g = sub(load_golden("g7_realdata"), name + "/")
+    net = make_net(pa, dev, sub(g, "p_"))
+    for i in range(2):
+        c = sub(g, "pair%d/" % i)
+        zero_grads(net)
+        y0 = torch.from_numpy(g["Y"][i:i + 1]).to(dev).requires_grad_(True)
+        t = torch.from_numpy(g["t"][i:i + 2]).to(dev)
+        sol = pa.odeint_adjoint(net, y0, t)
+        assert relerr(sol.detach().cpu().numpy(), c["sol"]) < TOL_DOPRI
+        (sol * torch.from_numpy(c["G"]).to(dev)).sum().backward()
+        assert relerr(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+        got = grads_of(net)
+        for k in KEYS:
+            assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+
+
+# --------------------------------------------------------------------------- oracle, larger sizes
+@pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1537, 24, 9), (513, 7, 3)])
+def test_rhs_vjp_vs_oracle(pa, dev, oracle, N, H, B):
+    p = rand_params(N, H, seed=N + H)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(1)
+    y = (r.rand(B, 1, N) * 3 - 1).astype(np.float32)
+    cot = r.randn(B, 1, N).astype(np.float32)
+    yt = torch.from_numpy(y).to(dev).requires_grad_(True)
+    out = net(torch.tensor(0.0), yt)
+    vjp_ref, gr_ref, f_ref = oracle.rhs_vjp(onet, y, cot)
+    assert relerr(out.detach().cpu().numpy(), f_ref) < TOL_RHS
+    out.backward(torch.from_numpy(cot).to(dev))
+    assert relerr(yt.grad.cpu().numpy(), vjp_ref) < TOL_RHS
+    got = grads_of(net)
+    for k in KEYS:
+        assert relerr(got[k], gr_ref[k]) < 2 * TOL_RHS, k
+    # prior branch
+    zero_grads(net)
+    out = net.prior_only_forward(torch.tensor(0.0), yt)
+    assert relerr(out.detach().cpu().numpy(), oracle.rhs(onet, y, prior_only=True)) < TOL_RHS
+
+
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+@pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1100, 16, 5)])
+def test_per_sample_solve_and_adjoint_vs_oracle(pa, dev, oracle, method, N, H, B):
+    p = rand_params(N, H, seed=7 * N + H, std=0.05)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(2)
+    y0 = r.rand(B, N).astype(np.float32)
+    t = np.stack([np.array([0.1 * b, 0.1 * b + 0.4 + 0.05 * b]) for b in range(B)]).astype(np.float32)
+    G = r.randn(B, 2, N).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method=method)                       # [B,2,N]
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=False)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)    # [2,B,1,N]
+    got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+    tol = TOL_DOPRI if method == "dopri5" else TOL_FIXED
+    gtol = TOL_DOPRI_GRAD if method == "dopri5" else TOL_FIXED
+    assert relerr(got, ref) < tol
+    (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < gtol
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < gtol, k
+
+
+def test_shared_control_multi_output_vs_oracle(pa, dev, oracle):
+    """validation()/find_gene_influences-style call: y0 [B,1,N], t [10] float64, one controller."""
+    N, H, B = 700, 20, 6
+    p = rand_params(N, H, seed=5, std=0.08)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    y0 = np.random.RandomState(3).rand(B, 1, N).astype(np.float32) - 0.25
+    t = np.arange(0, 1, 0.1)
+    ref, nfe_ref, _ = oracle.odeint(onet, y0, t, method="dopri5", return_stats=True)
+    sol, nfe, nsteps = pa.odeint(net, torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev), return_stats=True)
+    assert sol.shape == (10, B, 1, N)
+    assert relerr(sol.cpu().numpy(), ref) < TOL_DOPRI
+    assert int(nfe[0]) == 2 + 6 * int(nsteps[0])
+    assert abs(int(nfe[0]) - nfe_ref) <= 0.25 * nfe_ref   # same controller => similar step count
+
+
+# --------------------------------------------------------------------------- edge cases / errors
+def test_edge_cases(pa, dev):
+    p = rand_params(64, 8, seed=1)
+    net = make_net(pa, dev, p)
+    y0 = torch.rand(3, 1, 64, device=dev)
+    # single time point: solution is y0
+    sol = pa.odeint(net, y0, torch.tensor([0.5], device=dev))
+    assert torch.equal(sol[0], y0)
+    # y0 row of the output is exactly y0
+    sol = pa.odeint(net, y0, torch.tensor([0.0, 0.3, 0.9], device=dev), method="rk4")
+    assert torch.equal(sol[0], y0)
+    # non-monotone t -> AssertionError (misc.py:114-115)
+    with pytest.raises(AssertionError):
+        pa.odeint(net, y0, torch.tensor([0.0, 1.0, 0.5], device=dev))
+    # NaN state -> the reference trips 'underflow in dt nan' (rk_common.py:175)
+    bad = y0.clone()
+    bad[1, 0, 5] = float("nan")
+    with pytest.raises(AssertionError, match="underflow in dt"):
+        pa.odeint(net, bad, torch.tensor([0.0, 1.0], device=dev))
+    # max_num_steps
+    with pytest.raises(AssertionError, match="max_num_steps"):
+        pa.odeint(net, y0, torch.tensor([0.0, 50.0], device=dev), options={"max_num_steps": 2})
+
+
+# --------------------------------------------------------------------------- full-size properties
+def test_full_size_breast_properties(pa, dev, oracle):
+    """BASELINE config C4 (N=11165, H=40, B=256, dopri5 + adjoint): oracle on a row sample, plus
+    size-independent properties (batch invariance, VJP linearity, duplicated rows)."""
+    N, H, B = 11165, 40, 256
+    p = rand_params(N, H, seed=11, std=0.02)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(4)
+    y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
+    y0[7] = y0[3]                                   # duplicated trajectory
+    t = np.tile(np.array([[0.0, 0.0051]], np.float32), (B, 1))
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    tt = torch.from_numpy(t).to(dev)
+    sol = pa.odeint_adjoint(net, y0t, tt)
+    G = torch.from_numpy(r.randn(2, B, 1, N).astype(np.float32)).to(dev)
+    G[:, 7] = G[:, 3]
+    (sol * G).sum().backward()
+    s = sol.detach()
+    assert torch.equal(s[0], y0t.detach())
+    assert torch.equal(s[1, 7], s[1, 3]) and torch.equal(y0t.grad[7], y0t.grad[3])
+    # oracle on 3 sampled rows (per-sample semantics => rows are independent)
+    rows = [0, 100, 255]
+    ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
+    assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
+    adj_ref, _ = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
+                                                    method="dopri5", theta_in_norm=False)
+    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    # batch invariance: a sub-batch gives the same rows
+    sub_rows = list(range(16, 48))
+    s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
+    assert relerr(s2[1].cpu().numpy(), s[1, sub_rows].cpu().numpy()) < 2e-6
+    # parameter gradients == sum over sub-batches (linearity in the batch)
+    full = grads_of(net)
+    acc = {k: np.zeros_like(v) for k, v in full.items()}
+    for lo in range(0, B, 64):
+        zero_grads(net)
+        yy = y0t.detach()[lo:lo + 64].clone().requires_grad_(True)
+        ss = pa.odeint_adjoint(net, yy, tt[lo:lo + 64])
+        (ss * G[:, lo:lo + 64]).sum().backward()
+        for k, v in grads_of(net).items():
+            acc[k] += v
+    for k in KEYS:
+        assert relerr(acc[k], full[k]) < 2e-5, k
