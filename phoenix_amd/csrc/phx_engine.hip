@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/phoenix_hip.h"
 #include "phx_device.hpp"
@@ -418,6 +419,10 @@ __device__ __forceinline__ const double *trow(const double *t, const Dims &d, co
 {
     return cfg.t_per_sample ? t + (long long)b * d.T : t;
 }
+__device__ __forceinline__ const double *trowT(const double *t, int T, const SolveCfg &cfg, int b)
+{
+    return cfg.t_per_sample ? t + (long long)b * T : t;
+}
 
 // stage input of the fixed-grid methods, in the reference's own operation order
 // (fixed_grid.py:13-27, rk_common.py:96-103)
@@ -811,9 +816,11 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 }  // namespace
 
 // ========================================================================================
-// adjoint solve lives in its own translation unit section below
+// adjoint solve (v0) and the v1 MFMA kernels live in their own files
 // ========================================================================================
 #include "phx_adjoint.inc"
+#include "phx_mfma_common.inc"
+#include "phx_mfma_fwd.inc"
 
 // ========================================================================================
 // host side: C ABI
@@ -855,6 +862,101 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// v1 (MFMA) launch planning
+// ---------------------------------------------------------------------------------------------------
+constexpr size_t LDS_BUDGET = 163840 - 1024;
+
+bool force_v0()
+{
+    const char *e = getenv("PHX_ENGINE");
+    return e && strcmp(e, "v0") == 0;
+}
+
+// picks (NW, TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency
+bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hidden frag tiles / HT */,
+             size_t lds_per_block_extra, D1 *out)
+{
+    const int cus = num_cus();
+    if (cus <= 0 || H > 128 || force_v0()) return false;
+    const int HT = H <= 48 ? 3 : 8;
+    const size_t blkbytes = ((size_t)64 * HT * LROW + 32) * 4 + lds_per_block_extra;
+    const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
+    long long best_cost = -1;
+    D1 best{};
+    for (int NW = 4; NW >= 1; NW >>= 1)
+        for (int TPW = 1; TPW <= 4; TPW <<= 1) {
+            const int ntg = NW * TPW, TG = (ntt + ntg - 1) / ntg, Bt = 16 * ntg;
+            if (control == PHX_CTRL_SHARED && TG != 1) continue;
+            const size_t cb = ctl_bytes(Bt);
+            if (cb + blkbytes > LDS_BUDGET) continue;
+            const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
+            for (int NB = 1; NB <= NBmax; ++NB) {
+                const int G = (nblk + NB - 1) / NB;
+                if ((long long)TG * G > cus) continue;
+                const long long cost = (long long)TPW * NB * 1000 + (4 - NW) * 10 + (TG * G) / 64;
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
+                    best.TPW = TPW; best.G = G; best.TG = TG; best.nblk = nblk; best.ntg = ntg; best.Bt = Bt;
+                    best.nvec = nvec; best.BN = (long long)B * N;
+                }
+                break;  // smallest feasible NB for this (NW, TPW) is the cheapest
+            }
+        }
+    (void)fwidth;
+    if (best_cost < 0) return false;
+    *out = best;
+    return true;
+}
+
+struct Layout1 {
+    size_t total, cnt, part, zbuf, red, scratch, dtheta;
+};
+
+Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged per trajectory tile */, bool grads)
+{
+    Layout1 L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.cnt = take(4096);
+    L.part = take((size_t)d.TG * d.G * d.ntg * ftiles * 4 * 64 * 4);
+    L.zbuf = take((size_t)d.TG * d.ntg * ftiles * 4 * 64 * 4);
+    L.red = take((size_t)d.TG * d.G * d.Bt * 4 * 4);
+    L.scratch = take((size_t)d.TG * d.G * d.nvec * d.ntg * d.NB * 512 * 4);
+    const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
+    L.dtheta = take(grads ? PP * 4 * d.TG : 0);
+    L.total = off;
+    return L;
+}
+
+W1 make_w1(void *base, const Layout1 &L)
+{
+    char *p = (char *)base;
+    W1 w;
+    w.cnt = (unsigned long long *)(p + L.cnt);
+    w.abort_flag = (unsigned int *)(p + L.cnt + 2048);
+    w.part = (float *)(p + L.part);
+    w.zbuf = (float *)(p + L.zbuf);
+    w.red = (float *)(p + L.red);
+    w.scratch = (float *)(p + L.scratch);
+    w.dtheta = (float *)(p + L.dtheta);
+    return w;
+}
+
+size_t lds_bytes_v1(const D1 &d, size_t per_block_extra)
+{
+    return ((size_t)64 * d.HT * LROW + 32) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
+}
+
+template <typename K>
+bool set_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes) == hipSuccess;
+}
+
 }  // namespace
 
 extern "C" {
@@ -882,7 +984,14 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
 {
     if (N <= 0 || H <= 0 || B <= 0 || T < 0) return 0;
     const Dims d = make_dims(N, H, B, T, PHX_CTRL_PER_TRAJECTORY);
-    return make_layout(d, op).total;
+    size_t need = make_layout(d, op).total;
+    if (op == PHX_OP_ODEINT) {
+        D1 d1;
+        for (int ctl = 0; ctl < 2; ++ctl)
+            if (plan_v1(N, H, B, T, ctl, NVEC_FWD, 2, 0, &d1))
+                need = std::max(need, make_layout1(d1, 2 * d1.HT, false).total);
+    }
+    return need;
 }
 
 int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int prior_only, void *workspace,
@@ -932,17 +1041,38 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
         return PHX_ERR_BAD_ARG;
     if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
     if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
-    const Dims d = make_dims(p->N, p->H, B, T, o->control);
-    const Layout L = make_layout(d, PHX_OP_ODEINT);
-    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
-    const WS w = make_ws(workspace, L, d);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = grid_for(d.items);
-    if (grid <= 0) return PHX_ERR_LAUNCH;
     SolveCfg cfg;
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    {   // v1: MFMA kernels with LDS-resident weights, when the shape fits
+        D1 d1;
+        if (plan_v1(p->N, p->H, B, T, o->control, NVEC_FWD, 2, 0, &d1)) {
+            const Layout1 L1 = make_layout1(d1, 2 * d1.HT, false);
+            if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
+            const W1 w1 = make_w1(workspace, L1);
+            const size_t lds = lds_bytes_v1(d1, 0);
+            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
+            if (d1.HT == 3) {
+                if (!set_lds(k1_solve_fwd<3>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL(k1_solve_fwd<3>, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status,
+                                   nfe, nsteps);
+            } else {
+                if (!set_lds(k1_solve_fwd<8>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL(k1_solve_fwd<8>, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status,
+                                   nfe, nsteps);
+            }
+            return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+        }
+    }
+    const Dims d = make_dims(p->N, p->H, B, T, o->control);
+    const Layout L = make_layout(d, PHX_OP_ODEINT);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     hipLaunchKernelGGL(k_solve_fwd, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, y0, t, sol, status, nfe,
                        nsteps);
