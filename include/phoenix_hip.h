@@ -116,6 +116,11 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
                                 int *status, int *nfe, int *nsteps, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* Diagnostic only (not part of the drop-in surface): with PHX_PROF=1 in the environment the v1 kernels
+ * write 16 per-workgroup segment timers (100 MHz ticks) into the workspace; this returns where. */
+int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset,
+                             int *n_workgroups, int *plan);
+
 #ifdef __cplusplus
 }
 #endif

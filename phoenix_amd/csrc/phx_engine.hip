@@ -867,6 +867,8 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
 // v1 (MFMA) launch planning
 // ---------------------------------------------------------------------------------------------------
 constexpr size_t LDS_BUDGET = 163840 - 1024;
+constexpr int NVEC_ADJ = 0;          // v1 adjoint not built yet
+constexpr size_t ADJ_LDS_EXTRA = 0;
 
 bool force_v0()
 {
@@ -885,7 +887,9 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
-    for (int NW = 4; NW >= 1; NW >>= 1)
+    int nwmax = (HT == 3 ? 8 : 4);
+    if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
+    for (int NW = nwmax; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 4; TPW <<= 1) {
             const int ntg = NW * TPW, TG = (ntt + ntg - 1) / ntg, Bt = 16 * ntg;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
@@ -895,7 +899,8 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
             for (int NB = 1; NB <= NBmax; ++NB) {
                 const int G = (nblk + NB - 1) / NB;
                 if ((long long)TG * G > cus) continue;
-                const long long cost = (long long)TPW * NB * 1000 + (4 - NW) * 10 + (TG * G) / 64;
+                // per-SIMD MFMA work ~ TPW*NB*ceil(NW/4); prefer 2 waves per SIMD (latency hiding)
+                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (8 - NW) * 10 + (TG * G) / 64;
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
@@ -912,7 +917,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
 }
 
 struct Layout1 {
-    size_t total, cnt, part, zbuf, red, scratch, dtheta;
+    size_t total, cnt, part, zbuf, red, scratch, dtheta, prof;
 };
 
 Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged per trajectory tile */, bool grads)
@@ -927,6 +932,7 @@ Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged 
     L.scratch = take((size_t)d.TG * d.G * d.nvec * d.ntg * d.NB * 512 * 4);
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
     L.dtheta = take(grads ? PP * 4 * d.TG : 0);
+    L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.total = off;
     return L;
 }
@@ -942,6 +948,8 @@ W1 make_w1(void *base, const Layout1 &L)
     w.red = (float *)(p + L.red);
     w.scratch = (float *)(p + L.scratch);
     w.dtheta = (float *)(p + L.dtheta);
+    const char *pe = getenv("PHX_PROF");
+    w.prof = (pe && pe[0] == '1') ? (unsigned long long *)(p + L.prof) : nullptr;
     return w;
 }
 
@@ -979,6 +987,20 @@ const char *phx_status_string(int s)
 }
 
 int phx_device_cus(void) { return num_cus(); }
+
+int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups,
+                             int *plan /* [NW, TPW, NB, G, TG, HT] */)
+{
+    D1 d1;
+    if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
+    const bool adj = op == PHX_OP_ADJOINT;
+    if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1)) return PHX_ERR_BAD_ARG;
+    const Layout1 L1 = make_layout1(d1, adj ? 4 * d1.HT : 2 * d1.HT, adj);
+    *offset = L1.prof;
+    *n_workgroups = d1.TG * d1.G;
+    if (plan) { plan[0] = d1.NW; plan[1] = d1.TPW; plan[2] = d1.NB; plan[3] = d1.G; plan[4] = d1.TG; plan[5] = d1.HT; }
+    return PHX_OK;
+}
 
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
 {
@@ -1055,14 +1077,18 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
             const size_t lds = lds_bytes_v1(d1, 0);
             if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-            if (d1.HT == 3) {
-                if (!set_lds(k1_solve_fwd<3>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL(k1_solve_fwd<3>, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status,
-                                   nfe, nsteps);
+            if (d1.HT == 3 && d1.NW == 8) {
+                if (!set_lds(k1_solve_fwd<3, 512>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
+                                   status, nfe, nsteps);
+            } else if (d1.HT == 3) {
+                if (!set_lds(k1_solve_fwd<3, 256>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<3, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
+                                   status, nfe, nsteps);
             } else {
-                if (!set_lds(k1_solve_fwd<8>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL(k1_solve_fwd<8>, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status,
-                                   nfe, nsteps);
+                if (!set_lds(k1_solve_fwd<8, 256>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
+                                   status, nfe, nsteps);
             }
             return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         }

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-segment time of the v1 persistent kernels (PHX_PROF=1), averaged over workgroups.
+usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PHX_PROF"] = "1"
+import bench  # noqa: E402
+from phoenix_amd import _lib, engine  # noqa: E402
+
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "breast"]
+which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+dev = torch.device("cuda:0")
+net, y0, t = bench.make_problem(wl, dev, 0)
+N, H, B = wl["N"], wl["H"], wl["B"]
+p = engine.Params(net.net_sums.linear_out.weight, net.net_sums.linear_out.bias, net.net_prods.linear_out.weight,
+                  net.net_prods.linear_out.bias, net.net_alpha_combine.linear_out.weight, net.gene_multipliers)
+y2 = y0.reshape(B, N).contiguous()
+t64 = t.double().contiguous()
+T = t64.shape[1]
+lib = _lib.load()
+off, nwg = C.c_size_t(0), C.c_int(0)
+plan = (C.c_int * 6)()
+op = _lib.OP_ODEINT if which == "fwd" else _lib.OP_ADJOINT
+rc = lib.phx_debug_profile_region(op, N, H, B, T, _lib.CTRL_PER_TRAJECTORY, C.byref(off), C.byref(nwg), plan)
+assert rc == 0, "no v1 plan for this shape"
+print("plan NW=%d TPW=%d NB=%d G=%d TG=%d HT=%d  workgroups=%d" % (*plan, nwg.value))
+G = torch.randn(T, B, N, device=dev) / (B * N)
+for rep in range(3):
+    sol, st, nfe, ns = engine.solve_forward(p, y2, t64, wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+    if which == "adj":
+        engine.solve_adjoint(p, t64, sol, G, wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+torch.cuda.synchronize()
+ws = engine._ws_cache[(dev.index, torch.cuda.current_stream().cuda_stream, op)]
+raw = ws[off.value: off.value + nwg.value * 16 * 8].cpu().numpy().view(np.uint64).reshape(nwg.value, 16)
+us = raw.astype(np.float64) / 100.0
+names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "s11", "s12", "s13", "s14", "s15"]
+tot = us.sum(1)
+print("per-workgroup total: mean %.1f us  min %.1f  max %.1f" % (tot.mean(), tot.min(), tot.max()))
+for i, n in enumerate(names):
+    if us[:, i].max() > 0:
+        print("  %-24s mean %8.1f us  min %8.1f  max %8.1f   (%4.1f%%)" % (n, us[:, i].mean(), us[:, i].min(), us[:, i].max(),
+                                                                       100 * us[:, i].mean() / tot.mean()))
+print("nfe/traj", int(nfe[0]), "batch evals", int(nfe.sum()) / B)
