@@ -821,6 +821,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_adjoint.inc"
 #include "phx_mfma_common.inc"
 #include "phx_mfma_fwd.inc"
+#include "phx_mfma_adj.inc"
 
 // ========================================================================================
 // host side: C ABI
@@ -867,8 +868,8 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
 // v1 (MFMA) launch planning
 // ---------------------------------------------------------------------------------------------------
 constexpr size_t LDS_BUDGET = 163840 - 1024;
-constexpr int NVEC_ADJ = 0;          // v1 adjoint not built yet
 constexpr size_t ADJ_LDS_EXTRA = 0;
+constexpr int ADJ_NW_CAP = 8;
 
 bool force_v0()
 {
@@ -878,7 +879,7 @@ bool force_v0()
 
 // picks (NW, TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency
 bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hidden frag tiles / HT */,
-             size_t lds_per_block_extra, D1 *out)
+             size_t lds_per_block_extra, D1 *out, size_t ctl_extra_per_traj = 0, int nw_cap = 8)
 {
     const int cus = num_cus();
     if (cus <= 0 || H > 128 || force_v0()) return false;
@@ -887,13 +888,13 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
-    int nwmax = (HT == 3 ? 8 : 4);
+    int nwmax = std::min(nw_cap, (HT == 3 ? 8 : 4));
     if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
     for (int NW = nwmax; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 4; TPW <<= 1) {
             const int ntg = NW * TPW, TG = (ntt + ntg - 1) / ntg, Bt = 16 * ntg;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
-            const size_t cb = ctl_bytes(Bt);
+            const size_t cb = ctl_bytes(Bt) + ctl_extra_per_traj * Bt;
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
             for (int NB = 1; NB <= NBmax; ++NB) {
@@ -920,18 +921,19 @@ struct Layout1 {
     size_t total, cnt, part, zbuf, red, scratch, dtheta, prof;
 };
 
-Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged per trajectory tile */, bool grads)
+Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged per trajectory tile */, bool grads,
+                     int zslots = 1)
 {
     Layout1 L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L.cnt = take(4096);
     L.part = take((size_t)d.TG * d.G * d.ntg * ftiles * 4 * 64 * 4);
-    L.zbuf = take((size_t)d.TG * d.ntg * ftiles * 4 * 64 * 4);
+    L.zbuf = take((size_t)zslots * d.TG * d.ntg * ftiles * 4 * 64 * 4);
     L.red = take((size_t)d.TG * d.G * d.Bt * 4 * 4);
     L.scratch = take((size_t)d.TG * d.G * d.nvec * d.ntg * d.NB * 512 * 4);
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
-    L.dtheta = take(grads ? PP * 4 * d.TG : 0);
+    L.dtheta = take(grads ? PP * 4 * d.TG * d.NW : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.total = off;
     return L;
@@ -994,8 +996,10 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     D1 d1;
     if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
     const bool adj = op == PHX_OP_ADJOINT;
-    if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1)) return PHX_ERR_BAD_ARG;
-    const Layout1 L1 = make_layout1(d1, adj ? 4 * d1.HT : 2 * d1.HT, adj);
+    if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1, adj ? 40 : 0,
+                 adj ? ADJ_NW_CAP : 8))
+        return PHX_ERR_BAD_ARG;
+    const Layout1 L1 = make_layout1(d1, adj ? 4 * d1.HT : 2 * d1.HT, adj, adj ? 7 : 1);
     *offset = L1.prof;
     *n_workgroups = d1.TG * d1.G;
     if (plan) { plan[0] = d1.NW; plan[1] = d1.TPW; plan[2] = d1.NB; plan[3] = d1.G; plan[4] = d1.TG; plan[5] = d1.HT; }
@@ -1012,6 +1016,12 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
         for (int ctl = 0; ctl < 2; ++ctl)
             if (plan_v1(N, H, B, T, ctl, NVEC_FWD, 2, 0, &d1))
                 need = std::max(need, make_layout1(d1, 2 * d1.HT, false).total);
+    }
+    if (op == PHX_OP_ADJOINT) {
+        D1 d1;
+        for (int ctl = 0; ctl < 2; ++ctl)
+            if (plan_v1(N, H, B, T, ctl, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP))
+                need = std::max(need, make_layout1(d1, 4 * d1.HT, true, 7).total);
     }
     return need;
 }
@@ -1117,17 +1127,53 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
         return PHX_ERR_BAD_ARG;
     if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
     if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
-    const Dims d = make_dims(p->N, p->H, B, T, o->control);
-    const Layout L = make_layout(d, PHX_OP_ADJOINT);
-    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
-    const WS w = make_ws(workspace, L, d);
     hipStream_t st = (hipStream_t)stream;
-    const int grid = grid_for(d.items);
-    if (grid <= 0) return PHX_ERR_LAUNCH;
     SolveCfg cfg;
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    {   // v1: MFMA kernels
+        D1 d1;
+        if (plan_v1(p->N, p->H, B, T, o->control, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP)) {
+            const Layout1 L1 = make_layout1(d1, 4 * d1.HT, true, 7);
+            if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
+            const W1 w1 = make_w1(workspace, L1);
+            const size_t lds = lds_bytes_v1(d1, ADJ_LDS_EXTRA) + (size_t)40 * d1.Bt;
+            const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
+            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            if (grads && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
+                return PHX_ERR_LAUNCH;
+            const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
+            if (d1.HT == 3 && d1.NW == 8) {
+                if (!set_lds(k1_solve_adj<3, 512>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
+                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            } else if (d1.HT == 3) {
+                if (!set_lds(k1_solve_adj<3, 256>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<3, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
+                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            } else {
+                if (!set_lds(k1_solve_adj<8, 256>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
+                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            }
+            if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+            if (grads) {
+                const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
+                const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+                hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, d1.TG * d1.NW, PP, p->N,
+                                   p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
+                if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+            }
+            return PHX_OK;
+        }
+    }
+    const Dims d = make_dims(p->N, p->H, B, T, o->control);
+    const Layout L = make_layout(d, PHX_OP_ADJOINT);
+    if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+    const WS w = make_ws(workspace, L, d);
+    const int grid = grid_for(d.items);
+    if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess) return PHX_ERR_LAUNCH;
     hipLaunchKernelGGL(k_solve_adj, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, t, y_saved, grad_y, adj_y0,
