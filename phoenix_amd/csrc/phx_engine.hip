@@ -869,7 +869,7 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
 // ---------------------------------------------------------------------------------------------------
 constexpr size_t LDS_BUDGET = 163840 - 1024;
 constexpr size_t ADJ_LDS_EXTRA = 0;
-constexpr int ADJ_NW_CAP = 8;
+constexpr int ADJ_NW_CAP = 4;   // the augmented kernel needs the 512-register budget of one wave per SIMD
 
 bool force_v0()
 {
@@ -918,19 +918,20 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
 }
 
 struct Layout1 {
-    size_t total, cnt, part, zbuf, red, scratch, dtheta, prof;
+    size_t total, cnt, part, zbuf, scratch, dtheta, prof, xbytes;
 };
 
-Layout1 make_layout1(const D1 &d, int ftiles /* hidden fragment tiles exchanged per trajectory tile */, bool grads,
-                     int zslots = 1)
+// ftiles: hidden fragment tiles exchanged per trajectory tile (2HT forward, 4HT adjoint)
+Layout1 make_layout1(const D1 &d, int ftiles, bool grads, int zslots = 1)
 {
     Layout1 L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t R = (size_t)d.ntg * ftiles * 4 + d.ntg;   // hidden rows + norm rows per group
     L.cnt = take(4096);
-    L.part = take((size_t)d.TG * d.G * d.ntg * ftiles * 4 * 64 * 4);
-    L.zbuf = take((size_t)zslots * d.TG * d.ntg * ftiles * 4 * 64 * 4);
-    L.red = take((size_t)d.TG * d.G * d.Bt * 4 * 4);
+    L.part = take((size_t)d.TG * d.G * R * 64 * 8);
+    L.zbuf = take((size_t)zslots * d.TG * R * 64 * 8);
+    L.xbytes = off - L.part;                                // granule buffers are zeroed before every launch
     L.scratch = take((size_t)d.TG * d.G * d.nvec * d.ntg * d.NB * 512 * 4);
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
     L.dtheta = take(grads ? PP * 4 * d.TG * d.NW : 0);
@@ -945,9 +946,8 @@ W1 make_w1(void *base, const Layout1 &L)
     W1 w;
     w.cnt = (unsigned long long *)(p + L.cnt);
     w.abort_flag = (unsigned int *)(p + L.cnt + 2048);
-    w.part = (float *)(p + L.part);
-    w.zbuf = (float *)(p + L.zbuf);
-    w.red = (float *)(p + L.red);
+    w.part = (unsigned long long *)(p + L.part);
+    w.zbuf = (unsigned long long *)(p + L.zbuf);
     w.scratch = (float *)(p + L.scratch);
     w.dtheta = (float *)(p + L.dtheta);
     const char *pe = getenv("PHX_PROF");
@@ -1086,6 +1086,7 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
             const W1 w1 = make_w1(workspace, L1);
             const size_t lds = lds_bytes_v1(d1, 0);
             if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
             if (d1.HT == 3 && d1.NW == 8) {
                 if (!set_lds(k1_solve_fwd<3, 512>, lds)) return PHX_ERR_LAUNCH;
@@ -1141,7 +1142,9 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
             const size_t lds = lds_bytes_v1(d1, ADJ_LDS_EXTRA) + (size_t)40 * d1.Bt;
             const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
             if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
-            if (grads && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
+            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            // the quadrature pass first-touches every element of every partial (plain stores) when T >= 2
+            if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
                 return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
             if (d1.HT == 3 && d1.NW == 8) {
