@@ -346,3 +346,79 @@ def test_full_size_breast_properties(pa, dev, oracle):
             acc[k] += v
     for k in KEYS:
         assert relerr(acc[k], full[k]) < 2e-5, k
+
+
+# --------------------------------------------------------------------------- engine variants
+@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2"])
+@pytest.mark.parametrize("method", ["rk4", "dopri5"])
+def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant, method):
+    """The v0 (VALU, grid-barrier) kernels remain the fallback for shapes the v1 (MFMA) plan rejects, and v1
+    has several workgroup geometries: every variant must pass the same oracle check."""
+    if variant == "v0":
+        monkeypatch.setenv("PHX_ENGINE", "v0")
+    else:
+        monkeypatch.setenv("PHX_V1_MAXNW", variant[-1])
+    N, H, B = 777, 12, 21
+    p = rand_params(N, H, seed=99, std=0.06)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(8)
+    y0 = r.rand(B, N).astype(np.float32)
+    t = np.stack([np.array([0.05 * b, 0.05 * b + 0.5]) for b in range(B)]).astype(np.float32)
+    G = r.randn(B, 2, N).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method=method)
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=False)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
+    got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+    tol = TOL_DOPRI if method == "dopri5" else TOL_FIXED
+    gtol = TOL_DOPRI_GRAD if method == "dopri5" else TOL_FIXED
+    assert relerr(got, ref) < tol
+    (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < gtol
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < gtol, k
+
+
+def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle):
+    """odeint_adjoint on a batched y0 with ONE controller (reference semantics) over several output times:
+    exercises the per-interval restarts, the jump a += grad_y[i-1] and the multi-step quadrature."""
+    N, H, B = 300, 10, 5
+    p = rand_params(N, H, seed=17, std=0.15)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(5)
+    y0 = (r.rand(B, 1, N) * 1.4 - 0.2).astype(np.float32)
+    t = np.array([0.0, 0.6, 1.1, 2.5], np.float32)
+    G = r.randn(4, B, 1, N).astype(np.float32)
+    ref = oracle.odeint(onet, y0, t, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+    y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+    assert relerr(sol.detach().cpu().numpy(), ref) < TOL_DOPRI
+    (sol * torch.from_numpy(G).to(dev)).sum().backward()
+    assert relerr(y0t.grad.cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+
+
+def test_wide_hidden_layer_paths(pa, dev, oracle):
+    """H = 120 (yeast config: 8 hidden tiles) and H = 200 (B-cell config: v0 fallback, weights do not fit LDS)."""
+    for N, H, B in ((600, 120, 3), (400, 200, 2)):
+        p = rand_params(N, H, seed=H, std=0.03)
+        net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+        r = np.random.RandomState(6)
+        y0 = r.rand(B, N).astype(np.float32)
+        t = np.tile(np.array([[0.0, 0.8]], np.float32), (B, 1))
+        G = r.randn(B, 2, N).astype(np.float32)
+        ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+        adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+        y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+        sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+        got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+        assert relerr(got, ref) < TOL_DOPRI, (N, H)
+        (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+        assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD, (N, H)
+        gg = grads_of(net)
+        for k in KEYS:
+            assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
