@@ -207,8 +207,8 @@ def main():
         # Units per launch = batch-evaluations = (sum_b nfe_b) / B.
         alg_fwd = (nfe_fwd / B) * (4 * P + 8 * B * N)
         alg_adj = (nfe_aug / B) * (8 * P + 16 * B * N)
-        dom = "k_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k_solve_fwd"
-        alg, ms = (alg_adj, adj_ms_avg) if dom == "k_solve_adj" else (alg_fwd, fwd_ms_avg)
+        dom = "k1_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"
+        alg, ms = (alg_adj, adj_ms_avg) if dom == "k1_solve_adj" else (alg_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": None,

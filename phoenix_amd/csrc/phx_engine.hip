@@ -884,7 +884,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     const int cus = num_cus();
     if (cus <= 0 || H > 128 || force_v0()) return false;
     const int HT = H <= 48 ? 3 : 8;
-    const size_t blkbytes = ((size_t)64 * HT * LROW + 32) * 4 + lds_per_block_extra;
+    const size_t blkbytes = (size_t)blk_floats(HT, H) * 4 + lds_per_block_extra;
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
@@ -901,7 +901,8 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
                 const int G = (nblk + NB - 1) / NB;
                 if ((long long)TG * G > cus) continue;
                 // per-SIMD MFMA work ~ TPW*NB*ceil(NW/4); prefer 2 waves per SIMD (latency hiding)
-                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (8 - NW) * 10 + (TG * G) / 64;
+                // tie-break: fewer trajectories per group = smaller exchange volume and fewer members per reduction
+                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + Bt / 4 + (8 - NW);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
@@ -957,7 +958,7 @@ W1 make_w1(void *base, const Layout1 &L)
 
 size_t lds_bytes_v1(const D1 &d, size_t per_block_extra)
 {
-    return ((size_t)64 * d.HT * LROW + 32) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
+    return (size_t)blk_floats(d.HT, d.H) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
 }
 
 template <typename K>
