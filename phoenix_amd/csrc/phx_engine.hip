@@ -902,7 +902,8 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
                 if ((long long)TG * G > cus) continue;
                 // per-SIMD MFMA work ~ TPW*NB*ceil(NW/4); prefer 2 waves per SIMD (latency hiding)
                 // tie-break: fewer trajectories per group = smaller exchange volume and fewer members per reduction
-                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + Bt / 4 + (8 - NW);
+                // (the forward kernel is lighter on registers and measured faster with two waves per SIMD)
+                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (nw_cap >= 8 ? (8 - NW) * 100 : 0) + Bt / 4;
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
