@@ -326,8 +326,9 @@ double phxo_optimal_step_size(double last_step, float error_ratio, double safety
     double er = (double)error_ratio;
     double exponent = 1.0 / (double)order;
     double factor = safety / pow(er, exponent);
-    if (!(factor > dfactor)) factor = dfactor; /* torch.max */
-    if (!(factor < ifactor)) factor = ifactor; /* torch.min */
+    /* torch.max / torch.min propagate NaN (a NaN error ratio makes dt NaN => 'underflow in dt') */
+    if (factor == factor && !(factor > dfactor)) factor = dfactor;
+    if (factor == factor && !(factor < ifactor)) factor = ifactor;
     return last_step * factor;
 }
 
