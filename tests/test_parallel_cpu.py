@@ -24,7 +24,8 @@ def _worker(rank, world, port, q):
     loss.backward()
     parallel.allreduce_grads(lin)
     (tot,) = parallel.allreduce_scalars(loss)
-    q.put((rank, lin.weight.grad.clone(), lin.bias.grad.clone(), float(tot), (lo, hi)))
+    # plain lists: tensors in an mp.Queue travel as shared-memory fds that die with the worker
+    q.put((rank, lin.weight.grad.tolist(), lin.bias.grad.tolist(), float(tot), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,8 +50,8 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     ranges = sorted(r[4] for r in res)
     assert ranges == [(0, 5), (5, 10)]
     for _, gw, gb, tot, _ in res:
-        assert torch.allclose(gw, lin.weight.grad, rtol=1e-5, atol=1e-6)
-        assert torch.allclose(gb, lin.bias.grad, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(torch.tensor(gw), lin.weight.grad, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(torch.tensor(gb), lin.bias.grad, rtol=1e-5, atol=1e-6)
         assert abs(tot - float(loss)) < 1e-5 * abs(float(loss))
 
 
