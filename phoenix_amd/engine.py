@@ -60,9 +60,16 @@ class Params:
 
 
 class Grads:
+    """One flat zero-initialised buffer carved into the six gradient tensors (the engine accumulates into them);
+    `flat` is also what a data-parallel all-reduce wants."""
+
     def __init__(self, p):
-        z = lambda x: torch.zeros_like(x)
-        self.Ws, self.bs, self.Wp, self.bp, self.WaT, self.g = z(p.Ws), z(p.bs), z(p.Wp), z(p.bp), z(p.WaT), z(p.g)
+        H, N = p.H, p.N
+        sizes = (H * N, H, H * N, H, 2 * H * N, N)
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=p.device)
+        parts = torch.split(self.flat, sizes)
+        self.Ws, self.bs, self.Wp, self.bp = parts[0].view(H, N), parts[1], parts[2].view(H, N), parts[3]
+        self.WaT, self.g = parts[4].view(2 * H, N), parts[5]
         self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g))
 
     def as_reference_layout(self, g_shape):

@@ -98,6 +98,8 @@ class _OdeintAdjointFn(torch.autograd.Function):
                                                         atol, per_sample, t_is_f32, max_steps)
         engine.raise_for_status(status)
         ctx.cfg = cfg
+        ctx.phx_params = p   # engine-layout views (incl. the transposed Wa copy) reused by backward
+        ctx.phx_versions = tuple(x._version for x in (ws, bs, wp, bp, wa, g))
         ctx.save_for_backward(t64, sol, ws, bs, wp, bp, wa, g)
         ctx.mark_non_differentiable(nfe)
         return sol, nfe
@@ -109,7 +111,9 @@ class _OdeintAdjointFn(torch.autograd.Function):
             grad_sol = torch.zeros_like(sol)
         (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj) = ctx.cfg
         a_method, a_rtol, a_atol = adj
-        p = engine.Params(ws, bs, wp, bp, wa, g)
+        p = ctx.phx_params
+        if ctx.phx_versions != tuple(x._version for x in (ws, bs, wp, bp, wa, g)):
+            p = engine.Params(ws, bs, wp, bp, wa, g)   # parameters were modified in place since forward
         need_p = any(ctx.needs_input_grad[3:])
         adj_y0, grads, status, _nfe, _ns = engine.solve_adjoint(
             p, t64, sol, grad_sol.contiguous(), a_method, control, a_rtol, a_atol, per_sample, t_is_f32,
