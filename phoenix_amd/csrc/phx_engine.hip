@@ -822,6 +822,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_mfma_common.inc"
 #include "phx_mfma_fwd.inc"
 #include "phx_mfma_adj.inc"
+#include "phx_mfma_eval.inc"
 
 // ========================================================================================
 // host side: C ABI
@@ -962,6 +963,63 @@ size_t lds_bytes_v1(const D1 &d, size_t per_block_extra)
     return (size_t)blk_floats(d.HT, d.H) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
 }
 
+
+// ---- v1 standalone evaluation (large batches, passes)
+struct PlanEval {
+    D1 d;
+    int npass;
+    size_t lds;
+};
+
+bool plan_eval(int N, int H, int B, int nbc_cap, PlanEval *out)
+{
+    const int cus = num_cus();
+    if (cus <= 0 || H > 128 || force_v0()) return false;
+    const int HT = H <= 48 ? 3 : 8;
+    const size_t blkbytes = (size_t)blk_floats(HT, H) * 4;
+    const size_t extra = 16 * 64 * 4;
+    if (blkbytes + extra > LDS_BUDGET) return false;
+    int NB = (int)std::min<size_t>((LDS_BUDGET - extra) / blkbytes, (size_t)nbc_cap);
+    const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
+    NB = std::min(NB, nblk);
+    int G = (nblk + NB - 1) / NB;
+    while (G > cus && NB < nbc_cap) { NB++; G = (nblk + NB - 1) / NB; }
+    if (G > cus || (size_t)NB * blkbytes + extra > LDS_BUDGET) return false;
+    const int NW = 4;
+    int TG = std::max(1, cus / G);
+    TG = std::min(TG, (ntt + NW - 1) / NW);
+    D1 &d = out->d;
+    d = D1{};
+    d.N = N; d.H = H; d.B = B; d.T = 0; d.HT = HT; d.NB = NB; d.NW = NW; d.TPW = 1; d.G = G; d.TG = TG;
+    d.nblk = nblk; d.ntg = NW; d.Bt = 16 * NW; d.nvec = 0; d.BN = (long long)B * N;
+    out->npass = (ntt + TG * NW - 1) / (TG * NW);
+    out->lds = (size_t)NB * blkbytes + extra;
+    return true;
+}
+
+struct LayoutE {
+    size_t total, cnt, part, zbuf, dtheta, xbytes;
+};
+
+LayoutE make_layout_eval(const PlanEval &pe, bool aug)
+{
+    const D1 &d = pe.d;
+    LayoutE L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t R = (size_t)d.NW * (aug ? 4 : 2) * d.HT * 4;
+    L.cnt = take(4096);
+    L.part = take((size_t)d.TG * d.G * R * 64 * 8);
+    L.zbuf = take((size_t)(aug ? pe.npass : 1) * d.TG * R * 64 * 8);
+    L.xbytes = off - L.part;
+    const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
+    L.dtheta = take(aug ? PP * 4 * d.TG * d.NW : 0);
+    L.total = off;
+    return L;
+}
+
+constexpr int EVAL_NBC_HT3 = 4, EVAL_NBC_HT8 = 1;
+
 template <typename K>
 bool set_lds(K kernel, size_t bytes)
 {
@@ -1019,6 +1077,15 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
             if (plan_v1(N, H, B, T, ctl, NVEC_FWD, 2, 0, &d1))
                 need = std::max(need, make_layout1(d1, 2 * d1.HT, false).total);
     }
+    if (op == PHX_OP_RHS_FORWARD) {
+        PlanEval pe;
+        if (plan_eval(N, H, B, 8, &pe)) need = std::max(need, make_layout_eval(pe, false).total);
+    }
+    if (op == PHX_OP_RHS_VJP) {
+        PlanEval pe;
+        if (plan_eval(N, H, B, H <= 48 ? EVAL_NBC_HT3 : EVAL_NBC_HT8, &pe))
+            need = std::max(need, make_layout_eval(pe, true).total);
+    }
     if (op == PHX_OP_ADJOINT) {
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl)
@@ -1032,11 +1099,37 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
                     size_t workspace_bytes, void *stream)
 {
     if (bad_params(p) || !y || !out || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    {   // v1: MFMA, weights staged once for all passes over the batch
+        PlanEval pe;
+        if (plan_eval(p->N, p->H, B, 8, &pe)) {
+            const LayoutE L1 = make_layout_eval(pe, false);
+            if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
+            char *base = (char *)workspace;
+            W1 w1{};
+            w1.cnt = (unsigned long long *)(base + L1.cnt);
+            w1.abort_flag = (unsigned int *)(base + L1.cnt + 2048);
+            w1.part = (unsigned long long *)(base + L1.part);
+            w1.zbuf = (unsigned long long *)(base + L1.zbuf);
+            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
+            if (pe.d.HT == 3) {
+                if (!set_lds(k1_eval_fwd<3, 256>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_fwd<3, 256>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, out, prior_only,
+                                   pe.npass);
+            } else {
+                if (!set_lds(k1_eval_fwd<8, 256>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_fwd<8, 256>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, out, prior_only,
+                                   pe.npass);
+            }
+            return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+        }
+    }
     const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);
     const Layout L = make_layout(d, PHX_OP_RHS_FORWARD);
     if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
     const WS w = make_ws(workspace, L, d);
-    hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
@@ -1051,11 +1144,44 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
     if (bad_params(p) || !y || !cot || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
     if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
         return PHX_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (prior_only && grads && !vjp_y && !f_out) {   // the prior branch's backward: v1 MFMA parameter gradients
+        PlanEval pe;
+        if (plan_eval(p->N, p->H, B, p->H <= 48 ? EVAL_NBC_HT3 : EVAL_NBC_HT8, &pe)) {
+            const LayoutE L1 = make_layout_eval(pe, true);
+            if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
+            char *base = (char *)workspace;
+            W1 w1{};
+            w1.cnt = (unsigned long long *)(base + L1.cnt);
+            w1.abort_flag = (unsigned int *)(base + L1.cnt + 2048);
+            w1.part = (unsigned long long *)(base + L1.part);
+            w1.zbuf = (unsigned long long *)(base + L1.zbuf);
+            w1.dtheta = (float *)(base + L1.dtheta);
+            const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
+            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
+            if (pe.d.HT == 3) {
+                if (!set_lds(k1_eval_pgrad<3, EVAL_NBC_HT3>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_pgrad<3, EVAL_NBC_HT3>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot,
+                                   pe.npass, PP);
+            } else {
+                if (!set_lds(k1_eval_pgrad<8, EVAL_NBC_HT8>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_pgrad<8, EVAL_NBC_HT8>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot,
+                                   pe.npass, PP);
+            }
+            if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+            const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
+            const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, pe.d.TG * pe.d.NW, PP, p->N, p->H,
+                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
+            return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+        }
+    }
     const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);
     const Layout L = make_layout(d, PHX_OP_RHS_VJP);
     if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
     const WS w = make_ws(workspace, L, d);
-    hipStream_t st = (hipStream_t)stream;
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;

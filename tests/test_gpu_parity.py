@@ -422,3 +422,31 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
         gg = grads_of(net)
         for k in KEYS:
             assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
+
+
+@pytest.mark.parametrize("N,H,K", [(350, 40, 1000), (1537, 24, 333), (600, 120, 70)])
+def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
+    """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the v1
+    pass-structured MFMA kernels (forward for any batch, parameter gradients when the input needs no gradient)."""
+    p = rand_params(N, H, seed=3 * N + H, std=0.08)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(12)
+    X = (r.rand(K, 1, N) - 0.5).astype(np.float32)
+    tgt = (r.randn(K, 1, N) * 0.1).astype(np.float32)
+    Xt, tt = torch.from_numpy(X).to(dev), torch.from_numpy(tgt).to(dev)
+    pred = net.prior_only_forward(torch.tensor(0.0), Xt)
+    ref = oracle.rhs(onet, X, prior_only=True)
+    assert relerr(pred.detach().cpu().numpy(), ref) < TOL_RHS
+    loss = torch.mean((pred - tt) ** 2)
+    loss.backward()
+    cot = 2.0 * (ref - tgt) / ref.size
+    _, gr_ref, _ = oracle.rhs_vjp(onet, X, cot.astype(np.float32), prior_only=True)
+    got = grads_of(net)
+    for k in KEYS:
+        if np.max(np.abs(gr_ref[k])) == 0:
+            assert np.max(np.abs(got[k])) == 0, k
+        else:
+            assert relerr(got[k], gr_ref[k]) < 4 * TOL_RHS, k
+    # full RHS on the same batch (forward kernel, non-prior mode)
+    f = net(torch.tensor(0.0), Xt)
+    assert relerr(f.detach().cpu().numpy(), oracle.rhs(onet, X)) < TOL_RHS
