@@ -110,6 +110,33 @@ def cpu_baseline(wl, net, y0, t, G, seconds_budget=20.0):
             "nfe_forward": int(nf), "nfe_augmented": int(nb)}
 
 
+def full_training_step_ms(wl, net, y0, t, device, K=10000, reps=5):
+    import phoenix_amd
+
+    class Handler:
+        def __init__(self, b, tt, y):
+            self.b, self.device = (b, tt, y), b.device
+
+        def get_batch(self, bs):
+            return self.b
+
+    N = wl["N"]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    target = (y0 + 0.01 * torch.randn(y0.shape, generator=g).to(device))
+    X = (torch.rand(K, 1, N, generator=g) - 0.5).to(device)
+    prior_grad = (torch.randn(K, 1, N, generator=g) * 0.05).to(device)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-6)
+    h = Handler(y0, t, target)
+    times = []
+    for i in range(reps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        phoenix_amd.training_step(net, h, opt, wl["method"], y0.shape[0], False, False, X, prior_grad, 0.99)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(times[2:]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +149,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # under torchrun (RANK set) the collective path is always taken, also with a single rank, so that a 1-GPU
+    # box exercises exactly the code the 8-GPU run uses (RCCL init, barrier, flat gradient all-reduce)
+    use_dist = "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
@@ -135,7 +165,7 @@ def main():
     wl = WORKLOADS[args.workload]
     N, H, B = wl["N"], wl["H"], wl["B"]
     net, y0, t = make_problem(wl, device, seed=rank)          # every rank its own trajectories
-    if world > 1:   # replicas share parameters
+    if use_dist:   # replicas share parameters
         import torch.distributed as dist
         for p in net.parameters():
             dist.broadcast(p.data, 0)
@@ -145,20 +175,20 @@ def main():
     G[0].zero_()
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(net, y0, t, G, wl["method"], world)
+        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
     sync_all()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        one_step(net, y0, t, G, wl["method"], world)
+        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
     sync_all()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -192,7 +222,7 @@ def main():
 
     # whole-job value
     evals_per_step = (nfe_fwd + nfe_aug) * N      # gene x trajectory evaluations on this rank
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         te = torch.tensor([float(evals_per_step)], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.SUM)
@@ -228,12 +258,20 @@ def main():
                        "nfe_forward_per_step": nfe_fwd, "nfe_augmented_per_step": nfe_aug},
             "roofline": roofline,
         }
+        if world == 1:
+            # informational: the reference's full training_step (train_insilico.py:124-140) with its K = 10 000-row
+            # prior branch and an Adam step; NOT part of `value` (the metric counts ODE RHS evaluations only)
+            try:
+                out["training_step_ms"] = full_training_step_ms(wl, net, y0, t, device)
+            except Exception as exc:   # noqa: BLE001  (diagnostic extra must never break the bench line)
+                out["training_step_ms"] = None
+                out["training_step_error"] = repr(exc)[:200]
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(wl, net, y0, t, G)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -20,7 +20,7 @@ def flat_grads(module):
 def allreduce_grads(module, scale=None):
     """sum-all-reduce every parameter gradient as one flat fp32 buffer; `scale` (e.g. 1/world for a
     mean loss over the global batch) is applied after the reduction."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     ps, flat = flat_grads(module)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
