@@ -118,6 +118,9 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
 
 /* Diagnostic only (not part of the drop-in surface): with PHX_PROF=1 in the environment the v1 kernels
  * write 16 per-workgroup segment timers (100 MHz ticks) into the workspace; this returns where. */
+/* Diagnostic only: the next phx_odeint / phx_odeint_adjoint_backward call on this thread records these two
+ * hipEvent_t immediately before and after its solve kernel (not around its memset nodes / reduce kernel). */
+void phx_debug_set_kernel_events(void *ev_start, void *ev_stop);
 int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset,
                              int *n_workgroups, int *plan);
 

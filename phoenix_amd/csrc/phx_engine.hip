@@ -830,6 +830,10 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 namespace {
 
 int g_num_cus = -1;
+// diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+inline void ev_begin(hipStream_t st) { if (g_ev_start) hipEventRecord(g_ev_start, st); }
+inline void ev_end(hipStream_t st) { if (g_ev_stop) hipEventRecord(g_ev_stop, st); g_ev_start = nullptr; g_ev_stop = nullptr; }
 int num_cus()
 {
     if (g_num_cus < 0) {
@@ -1050,6 +1054,12 @@ const char *phx_status_string(int s)
 
 int phx_device_cus(void) { return num_cus(); }
 
+void phx_debug_set_kernel_events(void *ev_start, void *ev_stop)
+{
+    g_ev_start = (hipEvent_t)ev_start;
+    g_ev_stop = (hipEvent_t)ev_stop;
+}
+
 int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups,
                              int *plan /* [NW, TPW, NB, G, TG, HT] */)
 {
@@ -1216,6 +1226,7 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
             if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
             if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
+            ev_begin(st);
             if (d1.HT == 3 && d1.NW == 8) {
                 if (!set_lds(k1_solve_fwd<3, 512>, lds)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
@@ -1229,6 +1240,7 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
                 hipLaunchKernelGGL((k1_solve_fwd<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
                                    status, nfe, nsteps);
             }
+            ev_end(st);
             return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         }
     }
@@ -1239,8 +1251,10 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
+    ev_begin(st);
     hipLaunchKernelGGL(k_solve_fwd, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, y0, t, sol, status, nfe,
                        nsteps);
+    ev_end(st);
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
@@ -1275,6 +1289,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
             if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
                 return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
+            ev_begin(st);
             if (d1.HT == 3 && d1.NW == 8) {
                 if (!set_lds(k1_solve_adj<3, 512>, lds)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
@@ -1288,6 +1303,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
                 hipLaunchKernelGGL((k1_solve_adj<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
                                    grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             }
+            ev_end(st);
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
             if (grads) {
                 const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
@@ -1307,8 +1323,10 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
     if (grid <= 0) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess) return PHX_ERR_LAUNCH;
+    ev_begin(st);
     hipLaunchKernelGGL(k_solve_adj, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, t, y_saved, grad_y, adj_y0,
                        status, nfe, nsteps, grads ? 1 : 0);
+    ev_end(st);
     if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     if (grads) return launch_reduce(d, w, grads, st);
     return PHX_OK;
