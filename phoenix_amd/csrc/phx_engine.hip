@@ -924,6 +924,23 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     return true;
 }
 
+
+// Batches larger than one residency: per-trajectory control makes trajectories independent, so the host walks the
+// batch in chunks that the v1 plan accepts (pointers are offset, the [T,B,N] time stride stays B_total*N).
+int pick_chunk_v1(int N, int H, int B, int T, int control, bool adj)
+{
+    D1 d1;
+    auto ok = [&](int b) {
+        return adj ? plan_v1(N, H, b, T, control, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP)
+                   : plan_v1(N, H, b, T, control, NVEC_FWD, 2, 0, &d1);
+    };
+    if (ok(B)) return B;
+    if (control != PHX_CTRL_PER_TRAJECTORY) return 0;
+    for (int bc = 4096; bc >= 16; bc >>= 1)
+        if (bc < B && ok(bc)) return bc;
+    return 0;
+}
+
 struct Layout1 {
     size_t total, cnt, part, zbuf, scratch, dtheta, prof, xbytes;
 };
@@ -1083,9 +1100,11 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     size_t need = make_layout(d, op).total;
     if (op == PHX_OP_ODEINT) {
         D1 d1;
-        for (int ctl = 0; ctl < 2; ++ctl)
-            if (plan_v1(N, H, B, T, ctl, NVEC_FWD, 2, 0, &d1))
+        for (int ctl = 0; ctl < 2; ++ctl) {
+            const int bc = pick_chunk_v1(N, H, B, T, ctl, false);
+            if (bc > 0 && plan_v1(N, H, bc, T, ctl, NVEC_FWD, 2, 0, &d1))
                 need = std::max(need, make_layout1(d1, 2 * d1.HT, false).total);
+        }
     }
     if (op == PHX_OP_RHS_FORWARD) {
         PlanEval pe;
@@ -1098,9 +1117,11 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     }
     if (op == PHX_OP_ADJOINT) {
         D1 d1;
-        for (int ctl = 0; ctl < 2; ++ctl)
-            if (plan_v1(N, H, B, T, ctl, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP))
+        for (int ctl = 0; ctl < 2; ++ctl) {
+            const int bc = pick_chunk_v1(N, H, B, T, ctl, true);
+            if (bc > 0 && plan_v1(N, H, bc, T, ctl, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP))
                 need = std::max(need, make_layout1(d1, 4 * d1.HT, true, 7).total);
+        }
     }
     return need;
 }
@@ -1204,10 +1225,12 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
     return PHX_OK;
 }
 
-int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int T, const phx_solve_opts *o,
-               float *sol, int *status, int *nfe, int *nsteps, void *workspace, size_t workspace_bytes, void *stream)
+int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, int B, int T, const phx_solve_opts *o,
+               float *sol_all, int *status_all, int *nfe_all, int *nsteps_all, void *workspace, size_t workspace_bytes,
+               void *stream)
 {
-    if (bad_params(p) || !y0 || !t || !o || !sol || !status || !nfe || !nsteps || B <= 0 || T < 1 || !workspace)
+    if (bad_params(p) || !y0_all || !t_all || !o || !sol_all || !status_all || !nfe_all || !nsteps_all || B <= 0 ||
+        T < 1 || !workspace)
         return PHX_ERR_BAD_ARG;
     if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
     if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
@@ -1216,9 +1239,18 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
-    {   // v1: MFMA kernels with LDS-resident weights, when the shape fits
+    // v1: MFMA kernels with LDS-resident weights, when the shape fits (large batches: in chunks)
+    const int chunk_f = pick_chunk_v1(p->N, p->H, B, T, o->control, false);
+    for (int b0 = 0; chunk_f > 0 && b0 < B; b0 += chunk_f) {
         D1 d1;
-        if (plan_v1(p->N, p->H, B, T, o->control, NVEC_FWD, 2, 0, &d1)) {
+        const int bc = std::min(chunk_f, B - b0);
+        if (!plan_v1(p->N, p->H, bc, T, o->control, NVEC_FWD, 2, 0, &d1)) return PHX_ERR_BAD_ARG;
+        d1.BN = (long long)B * p->N;   // time stride of the caller's [T,B,N] arrays
+        {
+            const float *y0 = y0_all + (long long)b0 * p->N;
+            const double *t = o->t_per_sample ? t_all + (long long)b0 * T : t_all;
+            float *sol = sol_all + (long long)b0 * p->N;
+            int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
             const Layout1 L1 = make_layout1(d1, 2 * d1.HT, false);
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
             const W1 w1 = make_w1(workspace, L1);
@@ -1241,9 +1273,14 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
                                    status, nfe, nsteps);
             }
             ev_end(st);
-            return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+            if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         }
     }
+    if (chunk_f > 0) return PHX_OK;
+    const float *y0 = y0_all;
+    const double *t = t_all;
+    float *sol = sol_all;
+    int *status = status_all, *nfe = nfe_all, *nsteps = nsteps_all;
     const Dims d = make_dims(p->N, p->H, B, T, o->control);
     const Layout L = make_layout(d, PHX_OP_ODEINT);
     if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
@@ -1258,13 +1295,13 @@ int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
-int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int T, const phx_solve_opts *o,
-                                const float *y_saved, const float *grad_y, float *adj_y0, const phx_grads *grads,
-                                int *status, int *nfe, int *nsteps, void *workspace, size_t workspace_bytes,
-                                void *stream)
+int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B, int T, const phx_solve_opts *o,
+                                const float *y_saved_all, const float *grad_y_all, float *adj_y0_all,
+                                const phx_grads *grads, int *status_all, int *nfe_all, int *nsteps_all,
+                                void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (bad_params(p) || !t || !o || !y_saved || !grad_y || !adj_y0 || !status || !nfe || !nsteps || B <= 0 ||
-        T < 1 || !workspace)
+    if (bad_params(p) || !t_all || !o || !y_saved_all || !grad_y_all || !adj_y0_all || !status_all || !nfe_all ||
+        !nsteps_all || B <= 0 || T < 1 || !workspace)
         return PHX_ERR_BAD_ARG;
     if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
         return PHX_ERR_BAD_ARG;
@@ -1275,9 +1312,18 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
-    {   // v1: MFMA kernels
+    // v1: MFMA kernels (large batches: in chunks; every chunk's partials are added into `grads`)
+    const int chunk_a = pick_chunk_v1(p->N, p->H, B, T, o->control, true);
+    for (int b0 = 0; chunk_a > 0 && b0 < B; b0 += chunk_a) {
         D1 d1;
-        if (plan_v1(p->N, p->H, B, T, o->control, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP)) {
+        const int bc = std::min(chunk_a, B - b0);
+        if (!plan_v1(p->N, p->H, bc, T, o->control, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP)) return PHX_ERR_BAD_ARG;
+        d1.BN = (long long)B * p->N;
+        {
+            const double *t = o->t_per_sample ? t_all + (long long)b0 * T : t_all;
+            const float *y_saved = y_saved_all + (long long)b0 * p->N, *grad_y = grad_y_all + (long long)b0 * p->N;
+            float *adj_y0 = adj_y0_all + (long long)b0 * p->N;
+            int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
             const Layout1 L1 = make_layout1(d1, 4 * d1.HT, true, 7);
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
             const W1 w1 = make_w1(workspace, L1);
@@ -1312,9 +1358,13 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
                                    p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
                 if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
             }
-            return PHX_OK;
         }
     }
+    if (chunk_a > 0) return PHX_OK;
+    const double *t = t_all;
+    const float *y_saved = y_saved_all, *grad_y = grad_y_all;
+    float *adj_y0 = adj_y0_all;
+    int *status = status_all, *nfe = nfe_all, *nsteps = nsteps_all;
     const Dims d = make_dims(p->N, p->H, B, T, o->control);
     const Layout L = make_layout(d, PHX_OP_ADJOINT);
     if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;

@@ -450,3 +450,38 @@ def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     # full RHS on the same batch (forward kernel, non-prior mode)
     f = net(torch.tensor(0.0), Xt)
     assert relerr(f.detach().cpu().numpy(), oracle.rhs(onet, X)) < TOL_RHS
+
+
+def test_batches_larger_than_one_residency_are_chunked(pa, dev):
+    """B = 2000 trajectories at N = 11165 exceed what one persistent launch can hold co-resident; the host then
+    walks the batch in chunks (per-trajectory control => trajectories are independent).  Property: every row
+    equals the same row integrated in a small batch, forward and backward, and parameter gradients add up."""
+    N, H, B = 11165, 40, 2000
+    p = rand_params(N, H, seed=21, std=0.02)
+    net = make_net(pa, dev, p)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    y0 = (torch.randn(B, 1, N, generator=g) * 0.15 + 0.5).clamp_(0.03, 1.07).to(dev)
+    t = torch.tensor([[0.0, 0.0051]], dtype=torch.float32).repeat(B, 1).to(dev)
+    G = (torch.randn(2, B, 1, N, generator=g) / N).to(dev)
+    yb = y0.clone().requires_grad_(True)
+    sol = pa.odeint_adjoint(net, yb, t)
+    (sol * G).sum().backward()
+    full = grads_of(net)
+    rows = [0, 1023, 1024, 1999]            # both sides of the chunk boundary
+    zero_grads(net)
+    ys = y0[rows].clone().requires_grad_(True)
+    s2 = pa.odeint_adjoint(net, ys, t[rows])
+    (s2 * G[:, rows]).sum().backward()
+    assert relerr(s2.detach().cpu().numpy(), sol.detach()[:, rows].cpu().numpy()) < 2e-6
+    assert relerr(ys.grad.cpu().numpy(), yb.grad[rows].cpu().numpy()) < 2e-5
+    # gradient additivity over two halves
+    acc = {k: np.zeros_like(v) for k, v in full.items()}
+    for lo, hi in ((0, 1000), (1000, 2000)):
+        zero_grads(net)
+        yy = y0[lo:hi].clone().requires_grad_(True)
+        ss = pa.odeint_adjoint(net, yy, t[lo:hi])
+        (ss * G[:, lo:hi]).sum().backward()
+        for k, v in grads_of(net).items():
+            acc[k] += v
+    for k in KEYS:
+        assert relerr(acc[k], full[k]) < 3e-5, k
