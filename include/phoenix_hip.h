@@ -116,6 +116,13 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
                                 int *status, int *nfe, int *nsteps, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* prior_grad = X[K,N] @ P[N,N] with the prior matrix P in CSC form
+ * (colptr [N+1], rowidx/vals [nnz], rows ascending inside a column).  Replaces the reference's dense
+ * `torch.matmul(batch_for_prior, prior_mat)` (train_insilico.py:207-211) and the 0.5 GB dense matrix that
+ * `read_prior_matrix(..., sparse=True)` materialises (train_insilico.py:64-73).  out [K,N] is overwritten. */
+int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out,
+                      int K, int N, void *stream);
+
 /* Diagnostic only (not part of the drop-in surface): with PHX_PROF=1 in the environment the v1 kernels
  * write 16 per-workgroup segment timers (100 MHz ticks) into the workspace; this returns where. */
 /* Diagnostic only: the next phx_odeint / phx_odeint_adjoint_backward call on this thread records these two

@@ -823,6 +823,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_mfma_fwd.inc"
 #include "phx_mfma_adj.inc"
 #include "phx_mfma_eval.inc"
+#include "phx_prior.inc"
 
 // ========================================================================================
 // host side: C ABI
@@ -1070,6 +1071,15 @@ const char *phx_status_string(int s)
 }
 
 int phx_device_cus(void) { return num_cus(); }
+
+int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out, int K, int N,
+                       void *stream)
+{
+    if (!colptr || !rowidx || !vals || !X || !out || K <= 0 || N <= 0) return PHX_ERR_BAD_ARG;
+    const dim3 grid((N + 255) / 256, std::min(K, 2048));
+    hipLaunchKernelGGL(k_prior_spmm, grid, dim3(256), 0, (hipStream_t)stream, colptr, rowidx, vals, X, out, K, N);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
 
 void phx_debug_set_kernel_events(void *ev_start, void *ev_stop)
 {

@@ -15,6 +15,7 @@ Goldens:
   G5 training_step  one full reference training_step + Adam update         (train_insilico.py:124-140)
   G6 controller     _select_initial_step pieces, error ratio, step size, interpolation, norms
   G7 realdata       first pairs of shipped yeast / breast CSVs with a seeded H=8 net
+  G8 prior          read_prior_matrix (dense + triplet formats) and prior_grad = X @ P   (train_insilico.py:64-73,207-211)
 """
 import ast
 import os
@@ -382,10 +383,55 @@ def g7_realdata():
     save("g7_realdata", **out)
 
 
+# ---------------------------------------------------------------- G8 (row f1: prior targets)
+def load_reference_function(name):
+    src = open(os.path.join(REF, "train_insilico.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fn) == 1
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "<reference train_insilico.py:%s>" % name, "exec"), ns)
+    return ns[name]
+
+
+def g8_prior():
+    import tempfile
+    read_prior_matrix = load_reference_function("read_prior_matrix")   # train_insilico.py:64-73
+    out = {}
+    # (a) the shipped dense in-silico prior, 350 x 350, and the prior targets of a seeded batch
+    path = "/root/reference/ground_truth_simulator/clean_data/edge_prior_matrix_G350_noise_0.0.csv"
+    P = read_prior_matrix(path, sparse=False, num_genes=350)
+    r, c = np.nonzero(P.numpy())
+    torch.manual_seed(4)
+    X = torch.rand(16, 1, 350) - 0.5
+    out.update({"g350/rows": r, "g350/cols": c, "g350/vals": P.numpy()[r, c], "g350/X": X.numpy(),
+                "g350/prior_grad": torch.matmul(X, P).numpy(), "g350/csv_rows": np.genfromtxt(path, delimiter=",")[:3]})
+    # (b) triplet format (1-based i,j,v; duplicates are summed by sparse_coo_tensor.to_dense())
+    rs = np.random.RandomState(6)
+    n = 40
+    trip = np.stack([rs.randint(1, n + 1, 90), rs.randint(1, n + 1, 90), rs.choice([-1.0, 0.5, 1.0], 90)], 1)
+    trip[5] = trip[4]   # a duplicate coordinate
+    with tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False) as fh:
+        for a, b, v in trip:
+            fh.write("%d,%d,%g\n" % (a, b, v))
+        tpath = fh.name
+    Ps = read_prior_matrix(tpath, sparse=True, num_genes=n)
+    os.unlink(tpath)
+    Xs = torch.rand(8, 1, n) - 0.5
+    out.update({"trip/triplets": trip, "trip/dense": Ps.numpy(), "trip/X": Xs.numpy(),
+                "trip/prior_grad": torch.matmul(Xs, Ps).numpy(),
+                "trip/prior_grad_abs": torch.matmul(Xs, torch.abs(Ps)).numpy()})
+    save("g8_prior", **out)
+
+
 if __name__ == "__main__":
+    g8_prior() if "--only-g8" in sys.argv else None
+    if "--only-g8" in sys.argv:
+        sys.exit(0)
     g1_g2()
     g3_fixed()
     g4_dopri5()
     g5_training_step()
     g6_controller()
     g7_realdata()
+    g8_prior()

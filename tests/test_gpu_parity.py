@@ -485,3 +485,35 @@ def test_batches_larger_than_one_residency_are_chunked(pa, dev):
             acc[k] += v
     for k in KEYS:
         assert relerr(acc[k], full[k]) < 3e-5, k
+
+
+def test_f1_prior_targets_spmm(pa, dev):
+    """prior_grad = X @ P on the GPU (CSC SpMM) against the reference's dense matmul (golden G8) and, at
+    breast scale, against torch's dense product of the same sparse matrix (fp32 reference of the same op)."""
+    from phoenix_amd.prior import PriorMatrix, prior_targets
+    g = load_golden("g8_prior")
+    a = sub(g, "g350/")
+    P = PriorMatrix(a["rows"], a["cols"], a["vals"], 350, dev)
+    got = prior_targets(torch.from_numpy(a["X"]).to(dev), P)
+    assert got.shape == a["prior_grad"].shape
+    assert relerr(got.cpu().numpy(), a["prior_grad"]) < 2e-6
+    b = sub(g, "trip/")
+    r, c = np.nonzero(b["dense"])
+    Pt = PriorMatrix(r, c, b["dense"][r, c], 40, dev)
+    assert relerr(prior_targets(torch.from_numpy(b["X"]).to(dev), Pt).cpu().numpy(), b["prior_grad"]) < 2e-6
+    assert relerr(prior_targets(torch.from_numpy(b["X"]).to(dev), Pt.abs()).cpu().numpy(), b["prior_grad_abs"]) < 2e-6
+    # breast scale: N = 11165, 0.3 % dense {0, 0.5} prior, K = 10000 rows
+    N, K = 11165, 10000
+    rs = np.random.RandomState(1)
+    nnz = int(0.003 * N * N)
+    rr, cc = rs.randint(0, N, nnz), rs.randint(0, N, nnz)
+    Pb = PriorMatrix(rr, cc, np.full(nnz, 0.5, np.float32), N, dev)
+    X = torch.rand(K, 1, N, device=dev) - 0.5
+    out = prior_targets(X, Pb)
+    dense = Pb.to_dense().to(dev)
+    ref = torch.matmul(X[:64], dense)
+    assert relerr(out[:64].cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    # linearity property at full size: (X1 + X2) P = X1 P + X2 P
+    X2 = torch.rand(K, 1, N, device=dev) - 0.5
+    lhs = prior_targets(X + X2, Pb)
+    assert relerr((out + prior_targets(X2, Pb)).cpu().numpy()[:256], lhs.cpu().numpy()[:256]) < 5e-6
