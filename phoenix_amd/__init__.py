@@ -5,5 +5,8 @@ replaces `from torchdiffeq import odeint_adjoint as odeint` (train_insilico.py:1
 from .odeint import SOLVERS, odeint, odeint_adjoint, odeint_per_sample  # noqa: F401
 from .odenet import ODENet  # noqa: F401
 from .training import training_step  # noqa: F401
+from .data import DataHandler, readcsv, writecsv  # noqa: F401
+from .prior import PriorMatrix, prior_targets, read_prior_matrix  # noqa: F401
+from .analysis import gene_influence_scores  # noqa: F401
 
 __version__ = "0.1.0"

@@ -15,6 +15,8 @@ Goldens:
   G5 training_step  one full reference training_step + Adam update         (train_insilico.py:124-140)
   G6 controller     _select_initial_step pieces, error ratio, step size, interpolation, norms
   G7 realdata       first pairs of shipped yeast / breast CSVs with a seeded H=8 net
+  G9 datahandler    readcsv + DataHandler split / batches / validation sets, numpy stream seeded (datahandler.py, csvreader.py)
+  G10 analysis      gene-influence scoring loop (find_gene_influences.py:64-77) and calculate_trajectory (datahandler.py:310-340)
   G8 prior          read_prior_matrix (dense + triplet formats) and prior_grad = X @ P   (train_insilico.py:64-73,207-211)
 """
 import ast
@@ -424,10 +426,115 @@ def g8_prior():
     save("g8_prior", **out)
 
 
+# ---------------------------------------------------------------- G9 (row f2: csv format + DataHandler batching)
+def g9_datahandler():
+    """Reference DataHandler (datahandler.py) over a small synthetic CSV in the shipped wire format, with the global
+    numpy stream seeded: noise draws, train/validation split and every batch of one epoch are recorded."""
+    import contextlib
+    import io
+    from datahandler import DataHandler as RefDataHandler     # reference (needs matplotlib + figure_saver only at import)
+    csv_path = os.path.join(OUT, "g9_data.csv")
+    rs = np.random.RandomState(9)
+    dim, ntraj, L = 10, 7, 6
+    with open(csv_path, "w") as fh:
+        fh.write("%d,%d\n" % (dim, ntraj))
+        for tr in range(ntraj):
+            nvalid = L if tr % 3 else L - 1 - (tr % 2)          # some trajectories miss their last time points
+            for d in range(dim):
+                vals = rs.rand(L)
+                fh.write(",".join(("%.6f" % v) if i < nvalid else "" for i, v in enumerate(vals)) + "\n")
+            times = np.cumsum(rs.randint(1, 4, L)).astype(float)
+            fh.write(",".join(("%g" % v) if i < nvalid else "" for i, v in enumerate(times)) + "\n")
+    out = {}
+
+    def rec(key, b, t, y):
+        out[key + "/batch"], out[key + "/t"], out[key + "/target"] = b.numpy(), t.numpy(), y.numpy()
+
+    def epoch(h, key, bs):
+        h.reset_epoch()
+        k = 0
+        while not h.epoch_done:
+            rec("%s/b%d" % (key, k), *h.get_batch(bs))
+            k += 1
+        out[key + "/n_batches"] = k
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        np.random.seed(101)
+        h = RefDataHandler.fromcsv(csv_path, "cpu", 0.2, normalize=False, batch_type="single", noise=0.05,
+                                   scale_expression=2.0)
+        vd, vt, vy, nv = h.get_validation_set()
+        rec("A/val", vd, vt, vy)
+        out["A/n_val"] = nv
+        out["A/data_np0"] = h.data_np[0]
+        out["A/data_np0_0noise"] = h.data_np_0noise[0]
+        epoch(h, "A", 5)
+        rec("A/mu_val", *h.get_true_mu_set_pairwise(val_only=True, batch_type="single"))
+        rec("A/mu_all", *h.get_true_mu_set_pairwise(val_only=False, batch_type="single"))
+
+        np.random.seed(202)
+        h = RefDataHandler.fromcsv(csv_path, "cpu", 0.3, normalize=True, batch_type="trajectory", noise=0.0)
+        vd, vt, vy, nv = h.get_validation_set()
+        rec("B/val", vd, vt, vy)
+        out["B/n_val"] = nv
+        out["B/val_set_indx"] = np.asarray(h.val_set_indx)
+        epoch(h, "B", 1)
+        rec("B/mu_val", *h.get_true_mu_set_pairwise(val_only=True, batch_type="trajectory"))
+        rec("B/init_val", *h.get_true_mu_set_init_val_based())
+        out["B/times"] = h.get_times().numpy()
+
+        np.random.seed(303)
+        h = RefDataHandler.fromcsv(csv_path, "cpu", 0.2, batch_type="batch_time", batch_time=3, batch_time_frac=0.5)
+        vd, vt, vy, nv = h.get_validation_set()
+        rec("C/val", vd, vt, vy)
+        out["C/n_val"] = nv
+        epoch(h, "C", 4)
+    save("g9_datahandler", **out)
+
+
+# ---------------------------------------------------------------- G10 (row f3: batched analysis callers)
+def g10_analysis():
+    """(a) the scoring loop of find_gene_influences.py:64-77 (a script, so restated here call for call around the
+    reference's own odeint / ODENet) with the random draws recorded; (b) DataHandler.calculate_trajectory."""
+    import contextlib
+    import io
+    from datahandler import DataHandler as RefDataHandler
+    out = {}
+    N, H, S = 24, 6, 8
+    net = make_net(N, H, seed=31, dense_std=0.15, neg_g_frac=0.1)
+    out.update(pfx(params_np(net), "infl/p_"))
+    torch.manual_seed(12)
+    time_pts_to_project = torch.from_numpy(np.arange(0, 1, 0.1))
+    inits, perts, scores = [], [], []
+    with torch.no_grad():
+        for this_gene in range(N):
+            this_init = 1 * (torch.rand(S, 1, N) - 0.5)
+            inits.append(this_init.numpy().copy())
+            unpert_out = odeint_adjoint(net, this_init, time_pts_to_project, method="dopri5")
+            this_pert_col = 1 * (torch.rand(S) - 0.5)
+            perts.append(this_pert_col.numpy().copy())
+            this_init[:, 0, this_gene] = this_pert_col
+            pert_out = odeint_adjoint(net, this_init, time_pts_to_project, method="dopri5")
+            all_other_genes = [idx for idx in range(N) if idx != this_gene]
+            scores.append(torch.mean(abs(unpert_out[1:, :, :, all_other_genes] - pert_out[1:, :, :, all_other_genes])).item())
+    out.update({"infl/inits": np.stack(inits), "infl/perts": np.stack(perts), "infl/scores": np.array(scores)})
+
+    csv_path = os.path.join(OUT, "g9_data.csv")
+    net2 = make_net(10, 6, seed=5, dense_std=0.2)
+    out.update(pfx(params_np(net2), "traj/p_"))
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        np.random.seed(404)
+        h = RefDataHandler.fromcsv(csv_path, "cpu", 0.3, batch_type="trajectory", noise=0.0)
+        trajs, samples, grid = h.calculate_trajectory(net2, "dopri5", num_val_trajs=2)
+    out.update({"traj/trajectories": np.stack([x.numpy() for x in trajs]), "traj/samples": np.asarray(samples),
+                "traj/grid": grid})
+    save("g10_analysis", **out)
+
+
 if __name__ == "__main__":
-    g8_prior() if "--only-g8" in sys.argv else None
-    if "--only-g8" in sys.argv:
-        sys.exit(0)
+    for only, fn in (("--only-g8", "g8_prior"), ("--only-g9", "g9_datahandler"), ("--only-g10", "g10_analysis")):
+        if only in sys.argv:
+            globals()[fn]()
+            sys.exit(0)
     g1_g2()
     g3_fixed()
     g4_dopri5()
@@ -435,3 +542,5 @@ if __name__ == "__main__":
     g6_controller()
     g7_realdata()
     g8_prior()
+    g9_datahandler()
+    g10_analysis()

@@ -517,3 +517,38 @@ def test_f1_prior_targets_spmm(pa, dev):
     X2 = torch.rand(K, 1, N, device=dev) - 0.5
     lhs = prior_targets(X + X2, Pb)
     assert relerr((out + prior_targets(X2, Pb)).cpu().numpy()[:256], lhs.cpu().numpy()[:256]) < 5e-6
+
+
+# --------------------------------------------------------------------------- row f3: batched analysis callers
+def test_f3_gene_influence_scores(pa, dev):
+    """find_gene_influences.py:64-77 on the engine against the scores the reference produced (golden G10) from
+    the same random draws: 2N shared-control dopri5 solves of [8,1,24] with 10 outputs on a float64 grid."""
+    from phoenix_amd.analysis import gene_influence_scores
+    g = sub(load_golden("g10_analysis"), "infl/")
+    net = make_net(pa, dev, sub(g, "p_"))
+    inits, perts = torch.from_numpy(g["inits"]), torch.from_numpy(g["perts"])
+    got = gene_influence_scores(net, 24, "dopri5", n_random_inputs_per_gene=8, device=dev,
+                                draws=lambda k: (inits[k], perts[k]))
+    assert got.shape == g["scores"].shape
+    assert np.max(np.abs(got - g["scores"]) / np.abs(g["scores"])) < 2e-5
+    # default draws: runs end to end, positive finite scores, one per requested gene
+    some = gene_influence_scores(net, 24, "dopri5", n_random_inputs_per_gene=8, device=dev, genes=[3, 7])
+    assert some.shape == (2,) and np.all(np.isfinite(some)) and np.all(some > 0)
+
+
+def test_f3_calculate_trajectory(pa, dev):
+    """DataHandler.calculate_trajectory (datahandler.py:310-340): same samples (numpy stream) and the same 300-point
+    dense trajectories as the reference, all samples integrated in one launch."""
+    import os
+    from phoenix_amd.data import DataHandler
+    g = sub(load_golden("g10_analysis"), "traj/")
+    net = make_net(pa, dev, sub(g, "p_"))
+    csv = os.path.join(os.path.dirname(__file__), "golden", "g9_data.csv")
+    np.random.seed(404)
+    h = DataHandler.fromcsv(csv, dev, 0.3, batch_type="trajectory", noise=0.0)
+    trajs, samples, grid = h.calculate_trajectory(net, "dopri5", num_val_trajs=2)
+    assert [int(s) for s in samples] == [int(s) for s in g["samples"]]
+    assert np.array_equal(grid, g["grid"])
+    got = np.stack([x.numpy() for x in trajs])
+    assert got.shape == g["trajectories"].shape
+    assert relerr(got, g["trajectories"]) < TOL_DOPRI
