@@ -1152,8 +1152,8 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
             w1.abort_flag = (unsigned int *)(base + L1.cnt + 2048);
             w1.part = (unsigned long long *)(base + L1.part);
             w1.zbuf = (unsigned long long *)(base + L1.zbuf);
-            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
-            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            // counters + granule buffers are contiguous: one fill
+            if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
             if (pe.d.HT == 3) {
                 if (!set_lds(k1_eval_fwd<3, 256>, pe.lds)) return PHX_ERR_LAUNCH;
@@ -1199,8 +1199,8 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             w1.zbuf = (unsigned long long *)(base + L1.zbuf);
             w1.dtheta = (float *)(base + L1.dtheta);
             const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
-            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
-            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            // counters + granule buffers are contiguous: one fill
+            if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
             if (pe.d.HT == 3) {
                 if (!set_lds(k1_eval_pgrad<3, EVAL_NBC_HT3>, pe.lds)) return PHX_ERR_LAUNCH;
@@ -1265,8 +1265,8 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
             const W1 w1 = make_w1(workspace, L1);
             const size_t lds = lds_bytes_v1(d1, 0);
-            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
-            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            // counters + granule buffers are contiguous: one fill
+            if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
             ev_begin(st);
             if (d1.HT == 3 && d1.NW == 8) {
@@ -1339,8 +1339,8 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             const W1 w1 = make_w1(workspace, L1);
             const size_t lds = lds_bytes_v1(d1, ADJ_LDS_EXTRA) + (size_t)40 * d1.Bt;
             const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
-            if (hipMemsetAsync(w1.cnt, 0, 4096, st) != hipSuccess) return PHX_ERR_LAUNCH;
-            if (hipMemsetAsync(w1.part, 0, L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+            // counters + granule buffers are contiguous: one fill
+            if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             // the quadrature pass first-touches every element of every partial (plain stores) when T >= 2
             if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
                 return PHX_ERR_LAUNCH;

@@ -82,17 +82,23 @@ def _check_call(rc):
         raise RuntimeError("phoenix_amd: %s" % _lib.load().phx_status_string(rc).decode())
 
 
-def raise_for_status(status):
-    """Maps per-trajectory solver status onto the reference's exceptions (rk_common.py:154,175-176,
-    misc.py:114-115).  One device->host read."""
-    worst = int(status.max().item())
-    if worst == 0:
-        return
+def _raise(status, worst):
     bad = int((status != 0).nonzero()[0].item())
     msg = "%s (trajectory %d)" % (_lib.STATUS_TEXT.get(worst, "status %d" % worst), bad)
     if worst in (1, 2, 3, 4):
         raise AssertionError(msg)
     raise RuntimeError("phoenix_amd: " + msg)
+
+
+def raise_for_status(status):
+    """Maps per-trajectory solver status onto the reference's exceptions (rk_common.py:154,175-176,
+    misc.py:114-115).  One device->host read.  `status` is [B], or [L, B] for L consecutive launches (the forward
+    and backward solve of a training step share one stats block): the earliest failing launch is reported."""
+    if status.dim() == 1:
+        status = status.unsqueeze(0)
+    for launch, worst in enumerate(status.amax(dim=1).tolist()):
+        if worst != 0:
+            _raise(status[launch], int(worst))
 
 
 def rhs_forward(p, y, prior_only=False):
@@ -124,12 +130,19 @@ def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps):
                              int(t_is_f32), int(max_num_steps))
 
 
-def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0):
-    """y0 [B,N] f32, t64 [T] or [B,T] f64 (device) -> sol [T,B,N], status[B], nfe[B], nsteps[B]"""
+def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0, poison=False,
+                  stats=None):
+    """y0 [B,N] f32, t64 [T] or [B,T] f64 (device) -> sol [T,B,N], status[B], nfe[B], nsteps[B].
+    `poison` pre-fills `sol` with NaN so the outputs a failed trajectory never reached are NaN (a backward solve
+    launched before the status is read then stops at once with `non-finite values in state`)."""
     B, N = y0.shape
     T = t64.shape[-1]
-    sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
-    stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
+    if poison:
+        sol = torch.full((T, B, N), float("nan"), dtype=torch.float32, device=y0.device)
+    else:
+        sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
+    if stats is None:
+        stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
     ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device)
     o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)
     _check_call(_lib.load().phx_odeint(C.byref(p.c), _p(y0), _p(t64), B, T, C.byref(o), _p(sol), _p(stats[0]),
@@ -138,11 +151,12 @@ def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f3
 
 
 def solve_adjoint(p, t64, y_saved, grad_y, method, control, rtol, atol, t_per_sample, t_is_f32, want_grads=True,
-                  max_num_steps=0):
-    """y_saved, grad_y [T,B,N] -> adj_y0 [B,N], Grads, status, nfe, nsteps"""
+                  max_num_steps=0, stats=None):
+    """y_saved, grad_y [T,B,N] -> adj_y0 [B,N], Grads, status, nfe, nsteps.  `stats`: a zeroed int32 [3,B] to use."""
     T, B, N = y_saved.shape
     adj = torch.empty((B, N), dtype=torch.float32, device=y_saved.device)
-    stats = torch.zeros((3, B), dtype=torch.int32, device=y_saved.device)
+    if stats is None:
+        stats = torch.zeros((3, B), dtype=torch.int32, device=y_saved.device)
     grads = p.new_grads() if want_grads else None
     ws, nb = _workspace(_lib.OP_ADJOINT, p.N, p.H, B, T, y_saved.device)
     o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)

@@ -301,6 +301,17 @@ def test_edge_cases(pa, dev):
     # max_num_steps
     with pytest.raises(AssertionError, match="max_num_steps"):
         pa.odeint(net, y0, torch.tensor([0.0, 50.0], device=dev), options={"max_num_steps": 2})
+    # training path: a failed forward solve surfaces with the forward's message from backward(), where its status
+    # is read together with the backward solve's (one round trip per step); per-sample grids too
+    for t in (torch.tensor([0.0, 50.0], device=dev), torch.tensor([[0.0, 50.0]] * 3, device=dev)):
+        yg = y0.clone().requires_grad_(True)
+        sol = pa.odeint_adjoint(net, yg, t, options={"max_num_steps": 2})
+        with pytest.raises(AssertionError, match="max_num_steps"):
+            sol.sum().backward()
+    yg = bad.clone().requires_grad_(True)
+    sol = pa.odeint_adjoint(net, yg, torch.tensor([[0.0, 1.0]] * 3, device=dev))
+    with pytest.raises(AssertionError, match="underflow in dt .*trajectory 1"):
+        sol.sum().backward()
 
 
 # --------------------------------------------------------------------------- full-size properties
