@@ -32,8 +32,8 @@ WORKLOADS = {
                      desc="C2 in-silico 350-gene sim, 1024 trajectories x 4 intervals, fused 3/8-rule rk4 + adjoint"),
     "yeast": dict(N=2000, H=120, B=23, method="dopri5", t=[0.0, 5.0], init="reference",
                   desc="C3 yeast ~2000-gene oscillatory, 23 pairs, dopri5 + adjoint (reference 95%-sparse init)"),
-    "bcell": dict(N=14691, H=200, B=256, method="dopri5", t=[0.0, 1.0],
-                  desc="C5 B-cell ~15k-gene, H=200, 256 trajectories/GPU, dopri5 + adjoint"),
+    "bcell": dict(N=14691, H=200, B=256, method="dopri5", t=[0.0, 1.0], init="reference",
+                  desc="C5 B-cell ~15k-gene, H=200, 256 trajectories/GPU, dopri5 + adjoint (reference 95%-sparse init)"),
 }
 
 
@@ -242,9 +242,19 @@ def main():
         # Units per launch = batch-evaluations = (sum_b nfe_b) / B.
         alg_fwd = (nfe_fwd / B) * (4 * P + 8 * B * N)
         alg_adj = (nfe_aug / B) * (8 * P + 16 * B * N)
+        # ALGORITHMIC flops: 8BNH per RHS eval of the batch, 24BNH per augmented eval (forward + VJP
+        # w.r.t. y + VJP w.r.t. the parameters).
+        flop_fwd = (nfe_fwd / B) * 8.0 * B * N * H
+        flop_adj = (nfe_aug / B) * 24.0 * B * N * H
         dom = "k1_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"
-        alg, ms = (alg_adj, adj_ms_avg) if dom == "k1_solve_adj" else (alg_fwd, fwd_ms_avg)
+        alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == "k1_solve_adj" else (alg_fwd, flop_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
+        # Which roof binds: arithmetic intensity of the algorithmic figures against the fp32 ridge of the part
+        # (157.3 TFLOP/s f32-input MFMA / 8 TB/s HBM = 19.7 flop/B, MI355X_MICROARCH.md); SURVEY 8d: C4 at B = 256
+        # sits above it, the small-batch reference shapes below.
+        PEAK_HBM, PEAK_MFMA_F32 = 8000.0, 157.3
+        tflops = flop / (ms * 1e-3) / 1e12
+        mfma_bound = (flop / alg) > (PEAK_MFMA_F32 * 1e12) / (PEAK_HBM * 1e9)
         # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streams)
         traffic = None
@@ -255,15 +265,23 @@ def main():
                 traffic = (2.0 * pmc["FETCH_SIZE_KB_per_launch"][dom] + pmc["WRITE_SIZE_KB_per_launch"][dom]) * 1024.0
             except Exception:   # noqa: BLE001
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
+        roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
+                    "achieved": tflops if mfma_bound else achieved,
+                    "peak": PEAK_MFMA_F32 if mfma_bound else PEAK_HBM,
+                    "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                    "frac": tflops / PEAK_MFMA_F32 if mfma_bound else achieved / PEAK_HBM,
+                    "arithmetic_intensity_flop_per_byte": flop / alg,
+                    "hbm": {"achieved_GBps": achieved, "peak_GBps": PEAK_HBM, "frac": achieved / PEAK_HBM},
+                    "mfma_f32": {"achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_MFMA_F32,
+                                 "frac": tflops / PEAK_MFMA_F32, "algorithmic_flop_per_launch": flop},
+                    "traffic": traffic,
                     "traffic_source": "profiles/r1_%s_pmc_hbm.json (2*FETCH_SIZE + WRITE_SIZE)" % args.workload
                     if traffic else None,
                     "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
                     "forward": {"launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
-                                "batch_evals": nfe_fwd / B},
+                                "TFLOPs": flop_fwd / (fwd_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_fwd / B},
                     "adjoint": {"launch_ms": adj_ms_avg, "GBps": alg_adj / (adj_ms_avg * 1e-3) / 1e9,
-                                "batch_evals": nfe_aug / B}}
+                                "TFLOPs": flop_adj / (adj_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_aug / B}}
         out = {
             "metric": "ODE-RHS evals/sec (genes x trajectories)", "value": value,
             "unit": "gene*trajectory RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -888,9 +888,12 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
              size_t lds_per_block_extra, D1 *out, size_t ctl_extra_per_traj = 0, int nw_cap = 8)
 {
     const int cus = num_cus();
-    if (cus <= 0 || H > 128 || force_v0()) return false;
-    const int HT = H <= 48 ? 3 : 8;
-    const size_t blkbytes = (size_t)blk_floats(HT, H) * 4 + lds_per_block_extra;
+    if (cus <= 0 || force_v0()) return false;
+    // H > 128: the hidden layer is cut into HC chunks of Hc <= 128 rows whose weights take turns in LDS
+    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;
+    const int HT = Hc <= 48 ? 3 : 8;
+    if (HC > 1) nvec += (nvec >= NVEC_ADJ) ? (NVEC_ADJ_CH - NVEC_ADJ) : (NVEC_FWD_CH - NVEC_FWD);
+    const size_t blkbytes = (size_t)blk_floats(HT, Hc) * 4 + lds_per_block_extra;
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
@@ -914,7 +917,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
                     best_cost = cost;
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
                     best.TPW = TPW; best.G = G; best.TG = TG; best.nblk = nblk; best.ntg = ntg; best.Bt = Bt;
-                    best.nvec = nvec; best.BN = (long long)B * N;
+                    best.nvec = nvec; best.BN = (long long)B * N; best.HC = HC; best.Hc = Hc;
                 }
                 break;  // smallest feasible NB for this (NW, TPW) is the cheapest
             }
@@ -952,7 +955,7 @@ Layout1 make_layout1(const D1 &d, int ftiles, bool grads, int zslots = 1)
     Layout1 L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t R = (size_t)d.ntg * ftiles * 4 + d.ntg;   // hidden rows + norm rows per group
+    const size_t R = (size_t)d.ntg * ftiles * d.HC * 4 + d.ntg;   // hidden rows (all chunks) + norm rows per group
     L.cnt = take(4096);
     L.part = take((size_t)d.TG * d.G * R * 64 * 8);
     L.zbuf = take((size_t)zslots * d.TG * R * 64 * 8);
@@ -982,7 +985,7 @@ W1 make_w1(void *base, const Layout1 &L)
 
 size_t lds_bytes_v1(const D1 &d, size_t per_block_extra)
 {
-    return (size_t)blk_floats(d.HT, d.H) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
+    return (size_t)blk_floats(d.HT, d.Hc) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
 }
 
 
@@ -1014,6 +1017,7 @@ bool plan_eval(int N, int H, int B, int nbc_cap, PlanEval *out)
     d = D1{};
     d.N = N; d.H = H; d.B = B; d.T = 0; d.HT = HT; d.NB = NB; d.NW = NW; d.TPW = 1; d.G = G; d.TG = TG;
     d.nblk = nblk; d.ntg = NW; d.Bt = 16 * NW; d.nvec = 0; d.BN = (long long)B * N;
+    d.HC = 1; d.Hc = H;
     out->npass = (ntt + TG * NW - 1) / (TG * NW);
     out->lds = (size_t)NB * blkbytes + extra;
     return true;
@@ -1269,18 +1273,22 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
             ev_begin(st);
-            if (d1.HT == 3 && d1.NW == 8) {
-                if (!set_lds(k1_solve_fwd<3, 512>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_fwd<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
-                                   status, nfe, nsteps);
+            if (d1.HC > 1) {
+                if (!set_lds(k1_solve_fwd<8, 256, true>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
+                                   sol, status, nfe, nsteps);
+            } else if (d1.HT == 3 && d1.NW == 8) {
+                if (!set_lds(k1_solve_fwd<3, 512, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<3, 512, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
+                                   sol, status, nfe, nsteps);
             } else if (d1.HT == 3) {
-                if (!set_lds(k1_solve_fwd<3, 256>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_fwd<3, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
-                                   status, nfe, nsteps);
+                if (!set_lds(k1_solve_fwd<3, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<3, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
+                                   sol, status, nfe, nsteps);
             } else {
-                if (!set_lds(k1_solve_fwd<8, 256>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_fwd<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol,
-                                   status, nfe, nsteps);
+                if (!set_lds(k1_solve_fwd<8, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<8, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
+                                   sol, status, nfe, nsteps);
             }
             ev_end(st);
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
@@ -1346,18 +1354,22 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
                 return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
             ev_begin(st);
-            if (d1.HT == 3 && d1.NW == 8) {
-                if (!set_lds(k1_solve_adj<3, 512>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_adj<3, 512>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
-                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            if (d1.HC > 1) {
+                if (!set_lds(k1_solve_adj<8, 256, true>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
+                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            } else if (d1.HT == 3 && d1.NW == 8) {
+                if (!set_lds(k1_solve_adj<3, 512, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<3, 512, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
+                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             } else if (d1.HT == 3) {
-                if (!set_lds(k1_solve_adj<3, 256>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_adj<3, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
-                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+                if (!set_lds(k1_solve_adj<3, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<3, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
+                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             } else {
-                if (!set_lds(k1_solve_adj<8, 256>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_adj<8, 256>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved,
-                                   grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+                if (!set_lds(k1_solve_adj<8, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<8, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
+                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             }
             ev_end(st);
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;

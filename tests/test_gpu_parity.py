@@ -413,8 +413,45 @@ def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle):
         assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
 
 
+@pytest.mark.parametrize("N,H,B,method", [(700, 250, 5, "dopri5"), (300, 131, 20, "rk4"), (300, 131, 4, "dopri5")])
+def test_chunked_hidden_layer_shared_control_vs_oracle(pa, dev, oracle, N, H, B, method):
+    """H > 128: the hidden layer is processed in chunks whose weights take turns in LDS (H = 250 -> 125 + 125,
+    H = 131 -> 66 + 65; the library-wide limit is H <= 256).  Batched y0 with one controller over several output times, forward + adjoint, against the
+    oracle; and the VALU engine (PHX_ENGINE=v0) must agree with the chunked MFMA path."""
+    import os
+    p = rand_params(N, H, seed=H + B, std=0.04)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(5)
+    y0 = (r.rand(B, 1, N) * 1.2 - 0.1).astype(np.float32)
+    t = np.array([0.0, 0.4, 0.9, 1.3], np.float32)
+    G = r.randn(4, B, 1, N).astype(np.float32)
+    ref = oracle.odeint(onet, y0, t, method=method)
+    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method=method, theta_in_norm=False)
+    tol, gtol = (TOL_DOPRI, TOL_DOPRI_GRAD) if method == "dopri5" else (TOL_FIXED, TOL_FIXED)
+    results = {}
+    for engine in ("v1", "v0"):
+        if engine == "v0":
+            os.environ["PHX_ENGINE"] = "v0"
+        try:
+            zero_grads(net)
+            y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+            sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
+            (sol * torch.from_numpy(G).to(dev)).sum().backward()
+        finally:
+            os.environ.pop("PHX_ENGINE", None)
+        assert relerr(sol.detach().cpu().numpy(), ref) < tol, engine
+        assert relerr(y0t.grad.cpu().numpy(), adj_ref) < gtol, engine
+        gg = grads_of(net)
+        for k in KEYS:
+            assert relerr(gg[k], gr_ref[k]) < gtol, (engine, k)
+        results[engine] = gg
+    for k in KEYS:
+        assert relerr(results["v1"][k], results["v0"][k]) < gtol, k
+
+
 def test_wide_hidden_layer_paths(pa, dev, oracle):
-    """H = 120 (yeast config: 8 hidden tiles) and H = 200 (B-cell config: v0 fallback, weights do not fit LDS)."""
+    """H = 120 (yeast config: 8 hidden tiles, weights LDS resident) and H = 200 (B-cell config: two chunks of 100
+    hidden rows, re-staged per evaluation), per-sample control."""
     for N, H, B in ((600, 120, 3), (400, 200, 2)):
         p = rand_params(N, H, seed=H, std=0.03)
         net, onet = make_net(pa, dev, p), onet_of(oracle, p)

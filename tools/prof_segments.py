@@ -39,7 +39,7 @@ torch.cuda.synchronize()
 ws = engine._ws_cache[(dev.index, torch.cuda.current_stream().cuda_stream, op)]
 raw = ws[off.value: off.value + nwg.value * 16 * 8].cpu().numpy().view(np.uint64).reshape(nwg.value, 16)
 us = raw.astype(np.float64) / 100.0
-names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "quad: rest", "quad: mfma+loop", "quad: loads+act", "quad: stores", "s15"]
+names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "quad: rest", "quad: mfma+loop", "quad: loads+act", "quad: stores", "chunk weight staging"]
 tot = us.sum(1)
 print("per-workgroup total: mean %.1f us  min %.1f  max %.1f" % (tot.mean(), tot.min(), tot.max()))
 for i, n in enumerate(names):
