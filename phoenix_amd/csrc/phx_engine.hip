@@ -823,6 +823,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_mfma_fwd.inc"
 #include "phx_mfma_adj.inc"
 #include "phx_mfma_eval.inc"
+#include "phx_mfma_batch.inc"
 #include "phx_prior.inc"
 
 // ========================================================================================
@@ -1044,13 +1045,118 @@ LayoutE make_layout_eval(const PlanEval &pe, bool aug)
     return L;
 }
 
-constexpr int EVAL_NBC_HT3 = 4, EVAL_NBC_HT8 = 1;
+constexpr int EVAL_NBC_HT3_MAX = 4, EVAL_NBC_HT8 = 1;
+// gene blocks whose gradient accumulators a wave of k1_eval_pgrad keeps in registers (HT = 3); PHX_EVAL_NBC overrides
+int eval_nbc_ht3()
+{
+    int n = 2;
+    if (const char *e = getenv("PHX_EVAL_NBC")) n = atoi(e);
+    return std::min(EVAL_NBC_HT3_MAX, std::max(2, n));
+}
+
+// ---- exchange-free parameter gradients of the prior branch (phx_mfma_batch.inc)
+constexpr int BATCH_FWD_MIN_ROWS = 1024;   // smaller batches: the pass-structured k1_eval_fwd has less launch overhead
+struct PlanBatch {
+    D1 d;              // kernel A: gene tiles (NB blocks resident in LDS) x TG sweep groups
+    size_t ldsA;
+    int ntiles, chunk_tiles, KS, slabs;
+    long long Kp;
+    size_t part, hdt, dtheta, total;   // workspace offsets
+    size_t zl, total_fwd;              // forward path: per-chunk z rows
+};
+
+bool plan_batch(int N, int H, int B, PlanBatch *out)
+{
+    const int cus = num_cus();
+    if (cus <= 0 || H > 128 || force_v0()) return false;
+    if (const char *e = getenv("PHX_PGRAD")) if (strcmp(e, "v1") == 0) return false;
+    const int HT = H <= 48 ? 3 : 8;
+    const size_t blkbytes = (size_t)blk_floats(HT, H) * 4;
+    if (blkbytes > LDS_BUDGET) return false;
+    const int nblk = (N + 31) / 32;
+    const int NB = (int)std::min<size_t>(std::min<size_t>(LDS_BUDGET / blkbytes, 6), (size_t)nblk);
+    D1 &d = out->d;
+    d = D1{};
+    d.N = N; d.H = H; d.B = B; d.HT = HT; d.NB = NB; d.NW = 4; d.TPW = 1; d.nblk = nblk;
+    d.G = (nblk + NB - 1) / NB;
+    d.TG = std::max(1, cus / d.G);
+    d.HC = 1; d.Hc = H; d.BN = (long long)B * N;
+    out->ldsA = (size_t)NB * blkbytes;
+    out->ntiles = (B + 15) / 16;
+    out->Kp = (long long)out->ntiles * 16;
+    const size_t per_tile = (size_t)16 * HT * d.G * 64 * 4;           // FR rows x G members x 64 lanes
+    out->chunk_tiles = (int)std::max<size_t>(16, std::min<size_t>((size_t)out->ntiles, ((size_t)128 << 20) / per_tile));
+    out->slabs = (N + 63) / 64;
+    out->KS = std::max(1, std::min(8, (4 * cus) / out->slabs));   // ~4 workgroups per CU hide the tile-load latency
+    if (const char *e = getenv("PHX_PGRAD_KS")) out->KS = std::max(1, std::min(16, atoi(e)));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t PP = align_up((size_t)4 * H * N + N + 2 * H, 4);
+    out->part = take(per_tile * out->chunk_tiles);
+    out->hdt = take((size_t)4 * 16 * HT * out->Kp * 4);
+    out->dtheta = take(PP * 4 * out->KS);
+    out->total = off;
+    off = align_up(per_tile * out->chunk_tiles, 256);   // forward path reuses the partial buffer (half as many rows)
+    out->zl = take((size_t)out->chunk_tiles * 2 * HT * 4 * 64 * 4);
+    out->total_fwd = off;
+    return true;
+}
+
+template <int HT>
+int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
+                       char *base, hipStream_t st);
 
 template <typename K>
 bool set_lds(K kernel, size_t bytes)
 {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bytes) == hipSuccess;
+}
+
+template <int HT>
+int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
+                       char *base, hipStream_t st)
+{
+    float *part = (float *)(base + pb.part), *hdt = (float *)(base + pb.hdt), *dth = (float *)(base + pb.dtheta);
+    const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
+    if (hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
+    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
+        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+        hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA, st,
+                           to_net(p), pb.d, y, cot, part, t0, nt);
+        const int tasks = nt * HT * 4;
+        hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
+                           pb.d.G, t0, nt, pb.Kp);
+    }
+    hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
+                       pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP);
+    if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+    const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
+                       grads->WaT, grads->g, grads->bs, grads->bp);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+// prior_only_forward / ODENet.forward on a large batch: A (u, v partials) -> R (z rows) -> D (expansion) per chunk
+template <int HT>
+int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *y, float *out, int prior_only, char *base,
+                         hipStream_t st)
+{
+    float *part = (float *)(base + pb.part), *zl = (float *)(base + pb.zl);
+    if (!set_lds(k2_hidden_partials<HT, false>, pb.ldsA) || !set_lds(k2_expand<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    const dim3 grid(pb.d.TG * pb.d.G), blk(HT == 3 ? 512 : 256);
+    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
+        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+        hipLaunchKernelGGL((k2_hidden_partials<HT, false>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, (const float *)nullptr,
+                           part, t0, nt);
+        const int tasks = nt * HT * 4;
+        hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
+                           pb.d.G, t0, nt, pb.Kp);
+        hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt);
+    }
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -1121,13 +1227,17 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
         }
     }
     if (op == PHX_OP_RHS_FORWARD) {
+        PlanBatch pb;
+        if (B >= BATCH_FWD_MIN_ROWS && plan_batch(N, H, B, &pb)) need = std::max(need, pb.total_fwd);
         PlanEval pe;
         if (plan_eval(N, H, B, 8, &pe)) need = std::max(need, make_layout_eval(pe, false).total);
     }
     if (op == PHX_OP_RHS_VJP) {
+        PlanBatch pb;
+        if (plan_batch(N, H, B, &pb)) need = std::max(need, pb.total);
         PlanEval pe;
-        if (plan_eval(N, H, B, H <= 48 ? EVAL_NBC_HT3 : EVAL_NBC_HT8, &pe))
-            need = std::max(need, make_layout_eval(pe, true).total);
+        for (int nbc = (H <= 48 ? 2 : EVAL_NBC_HT8); nbc <= (H <= 48 ? EVAL_NBC_HT3_MAX : EVAL_NBC_HT8); ++nbc)
+            if (plan_eval(N, H, B, nbc, &pe)) need = std::max(need, make_layout_eval(pe, true).total);
     }
     if (op == PHX_OP_ADJOINT) {
         D1 d1;
@@ -1145,6 +1255,14 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
 {
     if (bad_params(p) || !y || !out || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    {   // large batches (the prior branch): exchange-free A -> R -> D chain (phx_mfma_batch.inc)
+        PlanBatch pb;
+        if (B >= BATCH_FWD_MIN_ROWS && plan_batch(p->N, p->H, B, &pb)) {
+            if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
+            return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, y, out, prior_only, (char *)workspace, st)
+                                : launch_batch_forward<8>(pb, p, y, out, prior_only, (char *)workspace, st);
+        }
+    }
     {   // v1: MFMA, weights staged once for all passes over the batch
         PlanEval pe;
         if (plan_eval(p->N, p->H, B, 8, &pe)) {
@@ -1190,9 +1308,16 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
     if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
         return PHX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (prior_only && grads && !vjp_y && !f_out) {   // the prior branch's backward: v1 MFMA parameter gradients
+    if (prior_only && grads && !vjp_y && !f_out) {   // the prior branch's backward: MFMA parameter gradients
+        PlanBatch pb;
+        if (plan_batch(p->N, p->H, B, &pb)) {       // exchange-free three-kernel path (phx_mfma_batch.inc)
+            if (workspace_bytes < pb.total) return PHX_ERR_WORKSPACE;
+            return pb.d.HT == 3 ? launch_batch_pgrad<3>(pb, p, y, cot, grads, (char *)workspace, st)
+                                : launch_batch_pgrad<8>(pb, p, y, cot, grads, (char *)workspace, st);
+        }
         PlanEval pe;
-        if (plan_eval(p->N, p->H, B, p->H <= 48 ? EVAL_NBC_HT3 : EVAL_NBC_HT8, &pe)) {
+        const int nbc3 = eval_nbc_ht3();
+        if (plan_eval(p->N, p->H, B, p->H <= 48 ? nbc3 : EVAL_NBC_HT8, &pe)) {
             const LayoutE L1 = make_layout_eval(pe, true);
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
             char *base = (char *)workspace;
@@ -1206,10 +1331,15 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             // counters + granule buffers are contiguous: one fill
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
-            if (pe.d.HT == 3) {
-                if (!set_lds(k1_eval_pgrad<3, EVAL_NBC_HT3>, pe.lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_eval_pgrad<3, EVAL_NBC_HT3>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot,
-                                   pe.npass, PP);
+            if (pe.d.HT == 3 && nbc3 == 2) {
+                if (!set_lds(k1_eval_pgrad<3, 2>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_pgrad<3, 2>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
+            } else if (pe.d.HT == 3 && nbc3 == 3) {
+                if (!set_lds(k1_eval_pgrad<3, 3>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_pgrad<3, 3>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
+            } else if (pe.d.HT == 3) {
+                if (!set_lds(k1_eval_pgrad<3, 4>, pe.lds)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_eval_pgrad<3, 4>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
             } else {
                 if (!set_lds(k1_eval_pgrad<8, EVAL_NBC_HT8>, pe.lds)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_pgrad<8, EVAL_NBC_HT8>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot,

@@ -472,10 +472,12 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
             assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
-@pytest.mark.parametrize("N,H,K", [(350, 40, 1000), (1537, 24, 333), (600, 120, 70)])
+@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100)])
 def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
-    """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the v1
-    pass-structured MFMA kernels (forward for any batch, parameter gradients when the input needs no gradient)."""
+    """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the exchange-free
+    MFMA chains of phx_mfma_batch.inc (forward from 1024 rows up, parameter gradients for any batch when the input
+    needs no gradient) and the pass-structured k1_eval_fwd below 1024 rows; H <= 48 and H = 120 tilings, a ragged
+    last gene block, several partial-buffer chunks at breast scale."""
     p = rand_params(N, H, seed=3 * N + H, std=0.08)
     net, onet = make_net(pa, dev, p), onet_of(oracle, p)
     r = np.random.RandomState(12)
