@@ -246,7 +246,7 @@ def main():
         # w.r.t. y + VJP w.r.t. the parameters).
         flop_fwd = (nfe_fwd / B) * 8.0 * B * N * H
         flop_adj = (nfe_aug / B) * 24.0 * B * N * H
-        dom = "k1_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"
+        dom = "k1_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"   # key into the PMC summary
         alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == "k1_solve_adj" else (alg_fwd, flop_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
         # Which roof binds: arithmetic intensity of the algorithmic figures against the fp32 ridge of the part
@@ -275,6 +275,7 @@ def main():
                     "mfma_f32": {"achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_MFMA_F32,
                                  "frac": tflops / PEAK_MFMA_F32, "algorithmic_flop_per_launch": flop},
                     "traffic": traffic,
+                    "measured_hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
                     "traffic_source": "profiles/r1_%s_pmc_hbm.json (2*FETCH_SIZE + WRITE_SIZE)" % args.workload
                     if traffic else None,
                     "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
