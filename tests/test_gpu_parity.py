@@ -359,6 +359,47 @@ def test_full_size_breast_properties(pa, dev, oracle):
         assert relerr(acc[k], full[k]) < 2e-5, k
 
 
+def test_full_size_bcell_properties(pa, dev, oracle):
+    """BASELINE config C5 (N=14691, H=200 -> two hidden chunks, B=256, dopri5 + adjoint) at full size: oracle on two
+    sampled rows, duplicated rows, sub-batch invariance, parameter gradients additive over sub-batches."""
+    N, H, B = 14691, 200, 256
+    p = rand_params(N, H, seed=21, std=0.004)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(9)
+    y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
+    y0[200] = y0[5]
+    t = np.tile(np.array([[0.0, 0.5]], np.float32), (B, 1))
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    tt = torch.from_numpy(t).to(dev)
+    sol = pa.odeint_adjoint(net, y0t, tt)
+    G = torch.from_numpy(r.randn(2, B, 1, N).astype(np.float32)).to(dev)
+    G[:, 200] = G[:, 5]
+    (sol * G).sum().backward()
+    s = sol.detach()
+    assert torch.equal(s[0], y0t.detach())
+    assert torch.equal(s[1, 200], s[1, 5]) and torch.equal(y0t.grad[200], y0t.grad[5])
+    rows = [1, 254]
+    ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
+    assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
+    adj_ref, _ = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
+                                                    method="dopri5", theta_in_norm=False)
+    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    sub_rows = list(range(100, 132))
+    s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
+    assert relerr(s2[1].cpu().numpy(), s[1, sub_rows].cpu().numpy()) < 2e-6
+    full = grads_of(net)
+    acc = {k: np.zeros_like(v) for k, v in full.items()}
+    for lo in range(0, B, 128):
+        zero_grads(net)
+        yy = y0t.detach()[lo:lo + 128].clone().requires_grad_(True)
+        ss = pa.odeint_adjoint(net, yy, tt[lo:lo + 128])
+        (ss * G[:, lo:lo + 128]).sum().backward()
+        for k, v in grads_of(net).items():
+            acc[k] += v
+    for k in KEYS:
+        assert relerr(acc[k], full[k]) < 2e-5, k
+
+
 # --------------------------------------------------------------------------- engine variants
 @pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2"])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
