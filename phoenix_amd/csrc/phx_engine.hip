@@ -894,7 +894,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;
     const int HT = Hc <= 48 ? 3 : 8;
     if (HC > 1) nvec += (nvec >= NVEC_ADJ) ? (NVEC_ADJ_CH - NVEC_ADJ) : (NVEC_FWD_CH - NVEC_FWD);
-    const size_t blkbytes = (size_t)(HC > 1 ? blk_floats_ch(HT, Hc) : blk_floats(HT, Hc)) * 4 + lds_per_block_extra;
+    const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4 + lds_per_block_extra;
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
@@ -965,7 +965,7 @@ Layout1 make_layout1(const D1 &d, int ftiles, bool grads, int zslots = 1)
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
     L.dtheta = take(grads ? PP * 4 * d.TG * d.NW : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
-    L.wimg = take(d.HC > 1 ? (size_t)d.nblk * d.HC * blk_floats_ch(d.HT, d.Hc) * 4 : 0);
+    L.wimg = take((size_t)d.nblk * d.HC * blk_floats_ch(d.HT, d.Hc) * 4);
     L.total = off;
     return L;
 }
@@ -988,8 +988,7 @@ W1 make_w1(void *base, const Layout1 &L)
 
 size_t lds_bytes_v1(const D1 &d, size_t per_block_extra)
 {
-    return (size_t)(d.HC > 1 ? blk_floats_ch(d.HT, d.Hc) : blk_floats(d.HT, d.Hc)) * 4 * d.NB + per_block_extra * d.NB +
-           ctl_bytes(d.Bt);
+    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB + per_block_extra * d.NB + ctl_bytes(d.Bt);
 }
 
 
@@ -1405,8 +1404,7 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
             // counters + granule buffers are contiguous: one fill
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-            if (d1.HC > 1)
-                hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
+            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
@@ -1489,8 +1487,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
                 return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-            if (d1.HC > 1)
-                hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
+            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
