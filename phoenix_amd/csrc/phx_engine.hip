@@ -1070,10 +1070,11 @@ struct PlanBatch {
 bool plan_batch(int N, int H, int B, PlanBatch *out)
 {
     const int cus = num_cus();
-    if (cus <= 0 || H > 128 || force_v0()) return false;
+    if (cus <= 0 || force_v0()) return false;
     if (const char *e = getenv("PHX_PGRAD")) if (strcmp(e, "v1") == 0) return false;
-    const int HT = H <= 48 ? 3 : 8;
-    const size_t blkbytes = (size_t)blk_floats(HT, H) * 4;
+    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;     // hidden chunks as in plan_v1: one chain per chunk
+    const int HT = Hc <= 48 ? 3 : 8;
+    const size_t blkbytes = (size_t)blk_floats(HT, Hc) * 4;
     if (blkbytes > LDS_BUDGET) return false;
     const int nblk = (N + 31) / 32;
     const int NB = (int)std::min<size_t>(std::min<size_t>(LDS_BUDGET / blkbytes, 6), (size_t)nblk);
@@ -1082,12 +1083,13 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     d.N = N; d.H = H; d.B = B; d.HT = HT; d.NB = NB; d.NW = 4; d.TPW = 1; d.nblk = nblk;
     d.G = (nblk + NB - 1) / NB;
     d.TG = std::max(1, cus / d.G);
-    d.HC = 1; d.Hc = H; d.BN = (long long)B * N;
+    d.HC = HC; d.Hc = Hc; d.BN = (long long)B * N;
     out->ldsA = (size_t)NB * blkbytes;
     out->ntiles = (B + 15) / 16;
     out->Kp = (long long)out->ntiles * 16;
     const size_t per_tile = (size_t)16 * HT * d.G * 64 * 4;           // FR rows x G members x 64 lanes
-    out->chunk_tiles = (int)std::max<size_t>(16, std::min<size_t>((size_t)out->ntiles, ((size_t)128 << 20) / per_tile));
+    // partials of one chunk: ~128 MB (Infinity Cache resident), but never fewer than 64 tiles per weight staging
+    out->chunk_tiles = (int)std::min<size_t>((size_t)out->ntiles, std::max<size_t>(64, ((size_t)128 << 20) / per_tile));
     out->slabs = (N + 63) / 64;
     out->KS = std::max(1, std::min(8, (4 * cus) / out->slabs));   // ~4 workgroups per CU hide the tile-load latency
     if (const char *e = getenv("PHX_PGRAD_KS")) out->KS = std::max(1, std::min(16, atoi(e)));
@@ -1123,16 +1125,19 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
     const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
     if (hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA)) return PHX_ERR_LAUNCH;
-    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
-        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
-        hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA, st,
-                           to_net(p), pb.d, y, cot, part, t0, nt);
-        const int tasks = nt * HT * 4;
-        hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
-                           pb.d.G, t0, nt, pb.Kp);
+    for (int ch = 0; ch < pb.d.HC; ++ch) {      // hidden chunks are independent slices of the same gradient
+        const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
+        for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
+            const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
+                               st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
+            const int tasks = nt * HT * 4;
+            hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
+                               pb.d.G, t0, nt, pb.Kp, hb, hc);
+        }
+        hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
+                           pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc);
     }
-    hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
-                       pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP);
     if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
@@ -1151,12 +1156,16 @@ int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *
     const dim3 grid(pb.d.TG * pb.d.G), blk(HT == 3 ? 512 : 256);
     for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
         const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
-        hipLaunchKernelGGL((k2_hidden_partials<HT, false>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, (const float *)nullptr,
-                           part, t0, nt);
-        const int tasks = nt * HT * 4;
-        hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
-                           pb.d.G, t0, nt, pb.Kp);
-        hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt);
+        for (int ch = 0; ch < pb.d.HC; ++ch) {
+            const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
+            hipLaunchKernelGGL((k2_hidden_partials<HT, false>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y,
+                               (const float *)nullptr, part, t0, nt, hb, hc);
+            const int tasks = nt * HT * 4;
+            hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
+                               pb.d.G, t0, nt, pb.Kp, hb, hc);
+            hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt, hb,
+                               hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0);
+        }
     }
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }

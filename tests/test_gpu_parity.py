@@ -513,7 +513,7 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
             assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
-@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100)])
+@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100), (300, 131, 90)])
 def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the exchange-free
     MFMA chains of phx_mfma_batch.inc (forward from 1024 rows up, parameter gradients for any batch when the input
