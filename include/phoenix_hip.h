@@ -123,6 +123,18 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out,
                       int K, int N, void *stream);
 
+/* the ground-truth Hill-kinetics simulator behind the reference's in-silico data
+ * (GraphGRN_core.R:425-486 emits one rate expression per gene -- ode_system_functions_*.csv -- and
+ * SimulationGRN_core_init_var.R:218-247 integrates them per sample).  The caller compiles the expressions to
+ * postfix programs: code [L][2] = (op, arg) with op 0 PUSHC consts[arg], 1 PUSHX x[arg], 2 ADD, 3 SUB, 4 MUL,
+ * 5 DIV, 6 NEG, 7 FACT with consts[arg..arg+2] = (B, K_n, n) of fAct (GraphGRN_core.R:431-436); off/len [N] give each
+ * gene's slice (len 0 = "input gene", rate 0).  phx_hill_rhs: out[B,N] = rates at x[B,N].  phx_hill_simulate:
+ * out[T,B,N] = states at times[T] (out[0] = x0), classical RK4 with equal sub-steps <= dt_max per interval.       */
+int phx_hill_rhs(const int *code, const int *off, const int *len, const float *consts, const float *x,
+                 float *out, int B, int N, void *stream);
+int phx_hill_simulate(const int *code, const int *off, const int *len, const float *consts, const float *x0,
+                      const double *times, int T, double dt_max, float *out, int B, int N, void *stream);
+
 /* Diagnostic only (not part of the drop-in surface): with PHX_PROF=1 in the environment the v1 kernels
  * write 16 per-workgroup segment timers (100 MHz ticks) into the workspace; this returns where. */
 /* Diagnostic only: the next phx_odeint / phx_odeint_adjoint_backward call on this thread records these two

@@ -8,5 +8,6 @@ from .training import training_step  # noqa: F401
 from .data import DataHandler, readcsv, writecsv  # noqa: F401
 from .prior import PriorMatrix, prior_targets, read_prior_matrix  # noqa: F401
 from .analysis import gene_influence_scores  # noqa: F401
+from .simulator import HillSystem, generate_dataset  # noqa: F401
 
 __version__ = "0.1.0"

@@ -825,6 +825,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_mfma_eval.inc"
 #include "phx_mfma_batch.inc"
 #include "phx_prior.inc"
+#include "phx_hill.inc"
 
 // ========================================================================================
 // host side: C ABI
@@ -1192,6 +1193,28 @@ const char *phx_status_string(int s)
 }
 
 int phx_device_cus(void) { return num_cus(); }
+
+int phx_hill_rhs(const int *code, const int *off, const int *len, const float *consts, const float *x, float *out, int B,
+                 int N, void *stream)
+{
+    if (!code || !off || !len || !consts || !x || !out || B <= 0 || N <= 0) return PHX_ERR_BAD_ARG;
+    const HillProg p{reinterpret_cast<const int2 *>(code), off, len, consts};
+    hipLaunchKernelGGL(k_hill_rhs, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, p, x, out, B, N);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+int phx_hill_simulate(const int *code, const int *off, const int *len, const float *consts, const float *x0,
+                      const double *times, int T, double dt_max, float *out, int B, int N, void *stream)
+{
+    if (!code || !off || !len || !consts || !x0 || !times || !out || B <= 0 || N <= 0 || T < 1 || !(dt_max > 0.0) ||
+        N > HILL_GPT * 1024)
+        return PHX_ERR_BAD_ARG;
+    const HillProg p{reinterpret_cast<const int2 *>(code), off, len, consts};
+    const int threads = std::min(1024, ((N + 63) / 64) * 64);
+    hipLaunchKernelGGL(k_hill_simulate, dim3(B), dim3(threads), sizeof(float) * (size_t)N, (hipStream_t)stream, p, x0, times, T,
+                       dt_max, out, B, N);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
 
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out, int K, int N,
                        void *stream)

@@ -1,0 +1,205 @@
+"""Row f4 of SURVEY.md section 8: the ground-truth Hill-kinetics simulator of the reference's in-silico data.
+
+The reference generates its 350 / 690-gene training data in R: `GraphGRN_core.R:425-486` turns the regulatory graph
+into one rate expression per gene (shipped as `ground_truth_simulator/clean_data/ode_system_functions_*.csv`, e.g.
+`((1 * fAct(GAL11, 0.408, 1.797)) * 1 - 1 * A1_ALPHA2) / 1`; AND = product, OR = a + b - ab, NOT = 1 - a are already
+spelled out in the text; `"input gene"` rows are held constant) and `SimulationGRN_core_init_var.R:203-247` draws
+initial states and integrates every sample with `deSolve::ode`.  R is not available in this image, so this module
+restates the simulator from those files: the expressions are compiled on the host into postfix programs and
+evaluated / integrated on the GPU (`phx_hill_rhs`, `phx_hill_simulate` in `csrc/phx_hill.inc`), and the result is
+written in the reference's CSV wire format (`csvreader.py:58-73`) so that `DataHandler.fromcsv` can train on it.
+Parity: the RHS is checked against Python's own evaluation of the shipped expression strings (fp64) and the
+trajectories against a tight-tolerance scipy solve of the same strings (golden G11); the R run itself cannot be
+reproduced here (its RNG draws are not recorded), which DESIGN.md states.
+"""
+import ast
+import csv
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, engine
+
+OPS = {"PUSHC": 0, "PUSHX": 1, "ADD": 2, "SUB": 3, "MUL": 4, "DIV": 5, "NEG": 6, "FACT": 7}
+MAX_STACK = 24   # HILL_STACK in csrc/phx_hill.inc
+
+
+def fact_constants(ec50, n):
+    """GraphGRN_core.R:431-434: B = (EC50^n - 1) / (2 EC50^n - 1), K_n = B - 1."""
+    b = (ec50 ** n - 1.0) / (2.0 * ec50 ** n - 1.0)
+    return b, b - 1.0, n
+
+
+class _Compiler(ast.NodeVisitor):
+    def __init__(self, index):
+        self.index, self.code, self.consts, self.depth, self.max_depth = index, [], [], 0, 0
+
+    def _push(self, op, arg=0):
+        self.code.append((OPS[op], arg))
+        self.depth += 1
+        self.max_depth = max(self.max_depth, self.depth)
+
+    def _const(self, *vals):
+        k = len(self.consts)
+        self.consts.extend(float(v) for v in vals)
+        return k
+
+    def visit_Expression(self, node):
+        self.visit(node.body)
+
+    def visit_Constant(self, node):
+        self._push("PUSHC", self._const(node.value))
+
+    def visit_Name(self, node):
+        if node.id not in self.index:
+            raise ValueError("unknown gene '%s' in a rate expression" % node.id)
+        self._push("PUSHX", self.index[node.id])
+
+    def visit_UnaryOp(self, node):
+        self.visit(node.operand)
+        if isinstance(node.op, ast.USub):
+            self.code.append((OPS["NEG"], 0))
+        elif not isinstance(node.op, ast.UAdd):
+            raise ValueError("unsupported unary operator in a rate expression")
+
+    def visit_BinOp(self, node):
+        ops = {ast.Add: "ADD", ast.Sub: "SUB", ast.Mult: "MUL", ast.Div: "DIV"}
+        if type(node.op) not in ops:
+            raise ValueError("unsupported operator in a rate expression")
+        self.visit(node.left)
+        self.visit(node.right)
+        self.code.append((OPS[ops[type(node.op)]], 0))
+        self.depth -= 1
+
+    def visit_Call(self, node):
+        if not (isinstance(node.func, ast.Name) and node.func.id == "fAct" and len(node.args) == 3):
+            raise ValueError("only fAct(TF, EC50, n) calls are supported in rate expressions")
+        self.visit(node.args[0])
+        ec50, n = (float(ast.literal_eval(a)) for a in node.args[1:])
+        self.code.append((OPS["FACT"], self._const(*fact_constants(ec50, n))))
+
+    def generic_visit(self, node):
+        raise ValueError("unsupported syntax in a rate expression: %s" % type(node).__name__)
+
+
+def read_ode_system(path):
+    """`ode_system_functions_*.csv`: columns node, eqn -> (names, expressions) in file order."""
+    with open(path, newline="") as fh:
+        rows = list(csv.DictReader(fh))
+    return [r["node"] for r in rows], [r["eqn"] for r in rows]
+
+
+class HillSystem:
+    """The compiled rate expressions of one regulatory network, resident on the device."""
+
+    def __init__(self, names, expressions, device="cuda"):
+        self.names, self.expressions = list(names), list(expressions)
+        self.N = len(self.names)
+        index = {n: i for i, n in enumerate(self.names)}
+        code, consts, off, length = [], [], [], []
+        self.is_input = np.zeros(self.N, bool)
+        for g, expr in enumerate(self.expressions):
+            off.append(len(code))
+            if expr.strip() == "input gene":            # GraphGRN_core.R:477-479
+                self.is_input[g] = True
+                length.append(0)
+                continue
+            c = _Compiler(index)
+            c.visit(ast.parse(expr, mode="eval"))
+            if c.max_depth > MAX_STACK:
+                raise ValueError("rate expression of %s needs a deeper evaluation stack (%d)" % (self.names[g], c.max_depth))
+            base = len(consts)
+            code.extend((op, arg + base if op in (OPS["PUSHC"], OPS["FACT"]) else arg) for op, arg in c.code)
+            consts.extend(c.consts)
+            length.append(len(c.code))
+        self.code_host = np.asarray(code, np.int32).reshape(-1, 2)
+        self.consts_host = np.asarray(consts, np.float64)
+        self.off_host, self.len_host = np.asarray(off, np.int32), np.asarray(length, np.int32)
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            self.code = torch.from_numpy(self.code_host).to(self.device)
+            self.consts = torch.from_numpy(self.consts_host.astype(np.float32)).to(self.device)
+            self.off = torch.from_numpy(self.off_host).to(self.device)
+            self.len = torch.from_numpy(self.len_host).to(self.device)
+
+    @classmethod
+    def from_csv(cls, path, device="cuda"):
+        return cls(*read_ode_system(path), device=device)
+
+    # ---- host interpreter of the same programs (fp64): test infrastructure for the compiler, not a compute path
+    def rhs_host(self, x):
+        x = np.asarray(x, np.float64)
+        out = np.zeros_like(x)
+        for g in range(self.N):
+            st = []
+            for op, arg in self.code_host[self.off_host[g]: self.off_host[g] + self.len_host[g]]:
+                if op == 0:
+                    st.append(np.full(x.shape[:-1], self.consts_host[arg]))
+                elif op == 1:
+                    st.append(x[..., arg])
+                elif op == 6:
+                    st[-1] = -st[-1]
+                elif op == 7:
+                    b, k, n = self.consts_host[arg: arg + 3]
+                    tn = np.where(st[-1] > 0, np.abs(st[-1]) ** n, 0.0)
+                    st[-1] = b * tn / (k + tn)
+                else:
+                    r = st.pop()
+                    st[-1] = st[-1] + r if op == 2 else st[-1] - r if op == 3 else st[-1] * r if op == 4 else st[-1] / r
+            if st:
+                out[..., g] = st[0]
+        return out
+
+    # ---- device
+    def _args(self):
+        p = engine._p
+        return p(self.code), p(self.off), p(self.len), p(self.consts)
+
+    def rhs(self, x):
+        """rates [B,N] at states x [B,N] (what `my_ode` returns, GraphGRN_core.R:441-470)."""
+        engine._require_gpu(x, "x")
+        x2 = x.detach().reshape(-1, self.N).contiguous().float()
+        out = torch.empty_like(x2)
+        engine._check_call(_lib.load().phx_hill_rhs(*self._args(), engine._p(x2), engine._p(out), x2.shape[0], self.N,
+                                                    engine._stream_ptr()))
+        return out.reshape(x.shape)
+
+    def simulate(self, x0, times, dt_max=0.01):
+        """states [T,B,N] at `times` (first row = x0), SimulationGRN_core_init_var.R:226-229,243-244."""
+        engine._require_gpu(x0, "x0")
+        x2 = x0.detach().reshape(-1, self.N).contiguous().float()
+        t64 = torch.as_tensor(np.asarray(times, np.float64), device=x2.device)
+        out = torch.empty((t64.numel(), x2.shape[0], self.N), dtype=torch.float32, device=x2.device)
+        engine._check_call(_lib.load().phx_hill_simulate(*self._args(), engine._p(x2), engine._p(t64), t64.numel(),
+                                                         C.c_double(dt_max), engine._p(out), x2.shape[0], self.N,
+                                                         engine._stream_ptr()))
+        return out
+
+    def sample_initial(self, numsamples, output_gene_var=1.0, rng=None):
+        """SimulationGRN_core_init_var.R:206-213: every gene ~ Beta(2/var, 2/var) shifted by its own U(-.25, .25),
+        clipped to [0, 1] (the reference draws external inputs from its input models; here they start like any
+        other gene and stay constant)."""
+        rng = np.random.default_rng() if rng is None else rng
+        a = 2.0 / output_gene_var
+        x = rng.beta(a, a, size=(numsamples, self.N)) + rng.uniform(-0.25, 0.25, size=(1, self.N))
+        return np.clip(x, 0.0, 1.0).astype(np.float32)
+
+
+def generate_dataset(system, numsamples, time_stamps=(0.0, 2.0, 3.0, 7.0, 9.0), expnoise=0.0, dt_max=0.01, rng=None,
+                     path=None):
+    """One in-silico data set like the reference's `example_creator...R` run: `numsamples` trajectories at
+    `time_stamps` (example_creator_for_chalmers_codebase_0noise.R:134-139), optional Gaussian measurement noise
+    (`addNormNoise`, SimulationGRN_core_init_var.R:1-3, 260-265); written with `writecsv` if `path` is given.
+    Returns (data_np, t_np) in `readcsv`'s shapes."""
+    from .data import writecsv
+    rng = np.random.default_rng() if rng is None else rng
+    x0 = torch.from_numpy(system.sample_initial(numsamples, rng=rng)).to(system.device)
+    sol = system.simulate(x0, time_stamps, dt_max).cpu().numpy()            # [T, S, N]
+    if expnoise > 0:
+        sol = sol + rng.normal(0.0, expnoise, size=sol.shape).astype(np.float32)
+    data_np = [sol[:, s].reshape(len(time_stamps), 1, system.N) for s in range(numsamples)]
+    t_np = [np.asarray(time_stamps, np.float64) for _ in range(numsamples)]
+    if path is not None:
+        writecsv(path, system.N, numsamples, data_np, t_np)
+    return data_np, t_np
