@@ -534,20 +534,15 @@ def g10_analysis():
 # ---------------------------------------------------------------- G11 (row f4: Hill-kinetics simulator)
 def g11_hill():
     """The shipped 350-gene rate expressions (reference DATA: ground_truth_simulator/clean_data/
-    ode_system_functions_350.csv, emitted by GraphGRN_core.R:425-486) are copied next to this script as a fixture;
-    their rates on random states are Python's own fp64 evaluation of the strings with fAct as defined in
+    ode_system_functions_350.csv, emitted by GraphGRN_core.R:425-486) go into the fixture as input arrays (node names,
+    expression strings); their rates on random states are Python's own fp64 evaluation of the strings with fAct as defined in
     GraphGRN_core.R:431-436, trajectories are scipy LSODA at rtol 1e-10 (the reference uses deSolve's lsoda).
     R cannot run here, so the reference's own simulated data set cannot be regenerated: parity of f4 is pinned
     against the expression files only."""
-    import shutil
     sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
     from oracle import hill_oracle
     from phoenix_amd.simulator import read_ode_system
-    src = "/root/reference/ground_truth_simulator/clean_data/ode_system_functions_350.csv"
-    dst = os.path.join(OUT, "g11_ode_system_350.csv")
-    shutil.copyfile(src, dst)
-    os.chmod(dst, 0o644)
-    names, exprs = read_ode_system(dst)
+    names, exprs = read_ode_system("/root/reference/ground_truth_simulator/clean_data/ode_system_functions_350.csv")
     rs = np.random.RandomState(11)
     X = rs.rand(16, len(names))
     X[0, :5] = 0.0                                   # fAct(0) = 0 branch
@@ -555,7 +550,7 @@ def g11_hill():
     times = np.array([0.0, 2.0, 3.0, 7.0, 9.0])      # example_creator_for_chalmers_codebase_0noise.R:134
     x0 = np.clip(rs.beta(2, 2, size=(3, len(names))) + rs.uniform(-0.25, 0.25, size=(1, len(names))), 0, 1)
     traj = np.stack([hill_oracle.simulate(names, exprs, x0[i], times) for i in range(3)], 1)   # [T, 3, N]
-    save("g11_hill", X=X, rates=rates, times=times, x0=x0, traj=traj)
+    save("g11_hill", names=np.array(names), eqns=np.array(exprs), X=X, rates=rates, times=times, x0=x0, traj=traj)
 
 
 if __name__ == "__main__":

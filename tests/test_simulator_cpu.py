@@ -8,13 +8,26 @@ import torch
 
 from conftest import load_golden
 
-CSV = os.path.join(os.path.dirname(__file__), "golden", "g11_ode_system_350.csv")
 
 
-def test_compiled_programs_match_the_expression_strings():
+def _system(g, device, tmp_path=None):
+    """HillSystem of the fixture's 350-gene network; through the CSV wire format when a directory is given."""
     from phoenix_amd.simulator import HillSystem
+    names, eqns = [str(x) for x in g["names"]], [str(x) for x in g["eqns"]]
+    if tmp_path is None:
+        return HillSystem(names, eqns, device=device)
+    import csv
+    path = os.path.join(str(tmp_path), "ode_system.csv")
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+        w.writerow(["node", "eqn"])
+        w.writerows(zip(names, eqns))
+    return HillSystem.from_csv(path, device=device)
+
+
+def test_compiled_programs_match_the_expression_strings(tmp_path):
     g = load_golden("g11_hill")
-    sys_ = HillSystem.from_csv(CSV, device="cpu")
+    sys_ = _system(g, "cpu", tmp_path)
     assert sys_.N == 350 and int(sys_.is_input.sum()) == 74          # 74 "input gene" rows in the shipped network
     got = sys_.rhs_host(g["X"])
     assert np.max(np.abs(got - g["rates"])) < 1e-12
@@ -43,10 +56,10 @@ def test_unsupported_syntax_is_rejected():
 def test_hill_rhs_and_trajectories_on_device(tmp_path):
     """phx_hill_rhs / phx_hill_simulate (fp32, RK4 sub-steps of 0.01) against the fp64 oracle values."""
     from phoenix_amd.data import readcsv
-    from phoenix_amd.simulator import HillSystem, generate_dataset
+    from phoenix_amd.simulator import generate_dataset
     g = load_golden("g11_hill")
     dev = torch.device("cuda:0")
-    sys_ = HillSystem.from_csv(CSV, device=dev)
+    sys_ = _system(g, dev)
     rates = sys_.rhs(torch.from_numpy(g["X"]).float().to(dev)).cpu().numpy()
     assert np.max(np.abs(rates - g["rates"])) < 5e-6
     traj = sys_.simulate(torch.from_numpy(g["x0"]).float().to(dev), g["times"]).cpu().numpy()
