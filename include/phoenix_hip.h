@@ -99,7 +99,8 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
 /* Replaces odeint(ODENet, y0, t, rtol, atol, method) (odeint.py:30-74; solvers.py:23-30,77-95;
  * rk_common.py:39-228; fixed_grid.py:6-38; dopri5.py; misc.py:47-103; interp.py).
  *   y0 [B,N]; t (double) [T] or [B,T] increasing or decreasing; sol [T,B,N] (sol[0] = y0).
- *   status [B] (int, phx_status per trajectory), nfe [B] (int, RHS evaluations), nsteps [B].   */
+ *   status [B] (int, phx_status per trajectory), nfe [B] (int, RHS evaluations), nsteps [B].
+ *   Outputs a failed trajectory (status != 0) never reached are set to NaN.                    */
 int phx_odeint(const phx_params *p, const float *y0, const double *t, int B, int T,
                const phx_solve_opts *opts, float *sol, int *status, int *nfe, int *nsteps,
                void *workspace, size_t workspace_bytes, void *stream);

@@ -811,6 +811,12 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
         nfe[b] = w.nfe[cb];
         nsteps[b] = w.nsteps[cb];
     }
+    // outputs a failed trajectory never reached are NaN (a backward solve launched on them stops at once)
+    for (long long e = gtid; e < d.BN; e += gsize) {
+        const int cb = shared ? 0 : (int)(e / d.N);
+        if (w.st[cb] != PHX_OK || gs.aborted)
+            for (int jo = max(w.out_idx[cb], 1); jo < d.T; ++jo) sol[(long long)jo * d.BN + e] = __int_as_float(0x7fc00000);
+    }
 }
 
 }  // namespace

@@ -130,17 +130,13 @@ def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps):
                              int(t_is_f32), int(max_num_steps))
 
 
-def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0, poison=False,
-                  stats=None):
+def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0, stats=None):
     """y0 [B,N] f32, t64 [T] or [B,T] f64 (device) -> sol [T,B,N], status[B], nfe[B], nsteps[B].
-    `poison` pre-fills `sol` with NaN so the outputs a failed trajectory never reached are NaN (a backward solve
-    launched before the status is read then stops at once with `non-finite values in state`)."""
+    The engine writes NaN into the outputs a failed trajectory never reached (a backward solve launched before the
+    status is read then stops at once)."""
     B, N = y0.shape
     T = t64.shape[-1]
-    if poison:
-        sol = torch.full((T, B, N), float("nan"), dtype=torch.float32, device=y0.device)
-    else:
-        sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
+    sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
     if stats is None:
         stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
     ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device)

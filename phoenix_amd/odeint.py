@@ -117,8 +117,7 @@ class _OdeintAdjointFn(torch.autograd.Function):
         # one zeroed stats block for both launches of the step: [0] forward, [1] backward; rows status/nfe/nsteps
         stats = torch.zeros((2 if defer else 1, 3, y2.shape[0]), dtype=torch.int32, device=y2.device)
         sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol,
-                                                        atol, per_sample, t_is_f32, max_steps, poison=defer,
-                                                        stats=stats[0])
+                                                        atol, per_sample, t_is_f32, max_steps, stats=stats[0])
         # The reference raises the solver's AssertionErrors synchronously.  When a backward pass is coming
         # (some input requires grad) the forward status is read together with the backward solve's status, in
         # ONE host<->device round trip per training step after both launches are queued: same exception (the

@@ -308,6 +308,22 @@ def test_edge_cases(pa, dev):
         sol = pa.odeint_adjoint(net, yg, t, options={"max_num_steps": 2})
         with pytest.raises(AssertionError, match="max_num_steps"):
             sol.sum().backward()
+    # ... and the outputs that trajectory never reached are NaN, the others are complete (both engines)
+    import os
+    from phoenix_amd import _lib, engine
+    pp = engine.Params(net.net_sums.linear_out.weight, net.net_sums.linear_out.bias, net.net_prods.linear_out.weight,
+                       net.net_prods.linear_out.bias, net.net_alpha_combine.linear_out.weight, net.gene_multipliers)
+    t3 = torch.tensor([[0.0, 0.5, 1.0]] * 3, device=dev, dtype=torch.float64)
+    for eng in ("v1", "v0"):
+        if eng == "v0":
+            os.environ["PHX_ENGINE"] = "v0"
+        try:
+            s3, st3, _, _ = engine.solve_forward(pp, bad.reshape(3, 64).contiguous(), t3, "dopri5", _lib.CTRL_PER_TRAJECTORY,
+                                                 1e-7, 1e-9, True, False)
+        finally:
+            os.environ.pop("PHX_ENGINE", None)
+        assert st3.tolist() == [0, 2, 0], eng
+        assert torch.isnan(s3[1:, 1]).all() and torch.isfinite(s3[:, [0, 2]]).all(), eng
     yg = bad.clone().requires_grad_(True)
     sol = pa.odeint_adjoint(net, yg, torch.tensor([[0.0, 1.0]] * 3, device=dev))
     with pytest.raises(AssertionError, match="underflow in dt .*trajectory 1"):
