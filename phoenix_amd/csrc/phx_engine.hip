@@ -926,7 +926,11 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
     for (int NW = nwmax; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 4; TPW <<= 1) {
-            const int ntg = NW * TPW, TG = (ntt + ntg - 1) / ntg, Bt = 16 * ntg;
+            const int slots = NW * TPW, TG = (ntt + slots - 1) / slots;
+            // a single group smaller than its wave slots: the spare waves become helpers of the exchange (the
+            // reduce-scatter splits a row's members over all NW waves), the tile count is what the batch needs
+            const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
+            const bool helpers = ntg < slots;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
             const size_t cb = ctl_bytes(Bt) + ctl_extra_per_traj * Bt;
             if (cb + blkbytes > LDS_BUDGET) continue;
@@ -937,7 +941,8 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
                 // per-SIMD MFMA work ~ TPW*NB*ceil(NW/4); prefer 2 waves per SIMD (latency hiding)
                 // tie-break: fewer trajectories per group = smaller exchange volume and fewer members per reduction
                 // (the forward kernel is lighter on registers and measured faster with two waves per SIMD)
-                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (nw_cap >= 8 ? (8 - NW) * 100 : 0) + Bt / 4;
+                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (nw_cap >= 8 ? (8 - NW) * 100 : 0) + Bt / 4 -
+                                       (helpers && TPW == 1 ? 50 : 0);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
@@ -1567,7 +1572,9 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             if (grads) {
                 const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
                 const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-                hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, d1.TG * d1.NW, PP, p->N,
+                hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta,
+                                   /* partials of waves that own tiles (helper waves of a single small group write none) */
+                                   d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW, PP, p->N,
                                    p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
                 if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
             }
