@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/_kstats.sh <python script> [args...]   -> top kernels by total time
+# usage (on the GPU box): bash tools/kernel_stats.sh <python script> [args...]   -> top kernels by total time
 R=$(pwd); OUT=$R/gpurun_out/kstats; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 "$R/$1" "${@:2}" > $OUT/log.txt 2>&1
