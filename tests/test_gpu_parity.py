@@ -375,6 +375,54 @@ def test_full_size_breast_properties(pa, dev, oracle):
         assert relerr(acc[k], full[k]) < 2e-5, k
 
 
+def test_full_size_insilico_vs_oracle(pa, dev, oracle):
+    """BASELINE config C2 at full size (N=350, H=40, 1024 trajectories x 4 intervals, fused 3/8-rule rk4 + adjoint):
+    every row against the oracle (per-sample semantics), gradients summed over the batch."""
+    N, H, B = 350, 40, 1024
+    p = rand_params(N, H, seed=2, std=0.05)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(3)
+    y0 = np.clip(r.beta(2, 2, size=(B, N)) + r.uniform(-0.25, 0.25, size=(1, N)), 0, 1).astype(np.float32)
+    t = np.tile(np.array([[0.0, 2.0, 3.0, 7.0, 9.0]], np.float32), (B, 1))
+    G = (r.randn(B, 5, N) / (B * N)).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="rk4")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="rk4", theta_in_norm=False)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method="rk4")
+    got = sol.detach().cpu().numpy().reshape(5, B, N).transpose(1, 0, 2)
+    assert relerr(got, ref) < TOL_FIXED
+    (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(5, B, 1, N).copy()).to(dev)).sum().backward()
+    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_FIXED
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < TOL_FIXED, k
+
+
+def test_full_size_yeast_vs_oracle(pa, dev, oracle):
+    """BASELINE config C3 at full size (N=2000, H=120, all 23 consecutive pairs, dopri5 + adjoint, reference-like
+    95 %-sparse weights, yeast value range): every row against the oracle."""
+    N, H, B = 2000, 120, 23
+    p = rand_params(N, H, seed=8, std=0.05)
+    r = np.random.RandomState(10)
+    for k in ("Ws", "Wp", "Wa"):
+        p[k] = (p[k] * (r.rand(*p[k].shape) < 0.05)).astype(np.float32)      # nn.init.sparse_(0.95) like
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    y0 = np.clip(r.randn(B, N) * 0.4, -2.5, 4.0).astype(np.float32)
+    t = np.tile(np.array([[0.0, 5.0]], np.float32), (B, 1))
+    G = (r.randn(B, 2, N) / (B * N)).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+    got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+    assert relerr(got, ref) < TOL_DOPRI
+    (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+
+
 def test_full_size_bcell_properties(pa, dev, oracle):
     """BASELINE config C5 (N=14691, H=200 -> two hidden chunks, B=256, dopri5 + adjoint) at full size: oracle on two
     sampled rows, duplicated rows, sub-batch invariance, parameter gradients additive over sub-batches."""
