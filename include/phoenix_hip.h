@@ -124,6 +124,15 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out,
                       int K, int N, void *stream);
 
+/* Fused head of the prior branch of training_step (train_insilico.py:134-135):
+ *   loss[0] = mean((prior_only_forward(X) - target)^2)  over B*N elements   (device float)
+ *   cot[B,N] = d loss / d prior_only_forward(X) = 2 (pred - target) / (B N)
+ * without materialising the prediction; `cot` is what phx_rhs_vjp(prior_only = 1) takes for the backward.
+ * Workspace: phx_workspace_bytes(PHX_OP_RHS_FORWARD, ...) for B >= 1024 rows; PHX_ERR_BAD_ARG when the batch chain
+ * cannot be planned (the caller then evaluates the unfused formula).                                              */
+int phx_prior_mse(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* the ground-truth Hill-kinetics simulator behind the reference's in-silico data
  * (GraphGRN_core.R:425-486 emits one rate expression per gene -- ode_system_functions_*.csv -- and
  * SimulationGRN_core_init_var.R:218-247 integrates them per sample).  The caller compiles the expressions to

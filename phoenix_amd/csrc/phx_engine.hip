@@ -1093,7 +1093,7 @@ struct PlanBatch {
     int ntiles, chunk_tiles, KS, slabs;
     long long Kp;
     size_t part, hdt, dtheta, total;   // workspace offsets
-    size_t zl, total_fwd;              // forward path: per-chunk z rows
+    size_t zl, losspart, total_fwd;    // forward path: per-chunk z rows, per-wave loss partials (fused MSE head)
 };
 
 bool plan_batch(int N, int H, int B, PlanBatch *out)
@@ -1131,6 +1131,7 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     out->total = off;
     off = align_up(per_tile * out->chunk_tiles, 256);   // forward path reuses the partial buffer (half as many rows)
     out->zl = take((size_t)out->chunk_tiles * 2 * HT * 4 * 64 * 4);
+    out->losspart = take((size_t)d.TG * d.G * 8 * sizeof(double));
     out->total_fwd = off;
     return true;
 }
@@ -1178,9 +1179,13 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
 // prior_only_forward / ODENet.forward on a large batch: A (u, v partials) -> R (z rows) -> D (expansion) per chunk
 template <int HT>
 int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *y, float *out, int prior_only, char *base,
-                         hipStream_t st)
+                         hipStream_t st, const float *target = nullptr, float *loss = nullptr)
 {
     float *part = (float *)(base + pb.part), *zl = (float *)(base + pb.zl);
+    double *loss_part = (double *)(base + pb.losspart);
+    const float cot_scale = (float)(2.0 / ((double)pb.d.B * (double)p->N));
+    if (target && hipMemsetAsync(loss_part, 0, sizeof(double) * (size_t)pb.d.TG * pb.d.G * 8, st) != hipSuccess)
+        return PHX_ERR_LAUNCH;
     if (!set_lds(k2_hidden_partials<HT, false>, pb.ldsA) || !set_lds(k2_expand<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
     const dim3 grid(pb.d.TG * pb.d.G), blk(HT == 3 ? 512 : 256);
     for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
@@ -1193,8 +1198,13 @@ int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *
             hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
                                pb.d.G, t0, nt, pb.Kp, hb, hc);
             hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt, hb,
-                               hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0);
+                               hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0, target, cot_scale, loss_part);
         }
+    }
+    if (target) {
+        const int nslots = pb.d.TG * pb.d.G * (HT == 3 ? 8 : 4);
+        hipLaunchKernelGGL(k2_loss_finish, dim3(1), dim3(64), 0, st, loss_part, nslots,
+                           1.0 / ((double)pb.d.B * (double)p->N), loss);
     }
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
@@ -1242,6 +1252,18 @@ int phx_hill_simulate(const int *code, const int *off, const int *len, const flo
     hipLaunchKernelGGL(k_hill_simulate, dim3(B), dim3(threads), sizeof(float) * (size_t)N, (hipStream_t)stream, p, x0, times, T,
                        dt_max, out, B, N);
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+int phx_prior_mse(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
+                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !X || !target || !cot || !loss || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    PlanBatch pb;
+    if (!plan_batch(p->N, p->H, B, &pb)) return PHX_ERR_BAD_ARG;   // callers fall back to the unfused formula
+    if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, X, cot, 1, (char *)workspace, st, target, loss)
+                        : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss);
 }
 
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out, int K, int N,

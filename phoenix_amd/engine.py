@@ -125,6 +125,28 @@ def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True):
     return (vjp.reshape(y.shape) if want_vjp_y else None), grads
 
 
+PRIOR_MSE_MIN_ROWS = 1024   # BATCH_FWD_MIN_ROWS of the library: below it the workspace query does not cover the chain
+
+
+def prior_mse(p, X, target):
+    """fused mean((prior_only_forward(X) - target)^2) and its cotangent; returns (loss [1], cot like X) or None when
+    the engine cannot plan the batch chain for this shape (caller falls back to the unfused formula)."""
+    _require_gpu(X, "X")
+    x2 = X.detach().reshape(-1, p.N).contiguous()
+    t2 = target.detach().reshape(-1, p.N).contiguous()
+    B = x2.shape[0]
+    if B < PRIOR_MSE_MIN_ROWS or t2.shape != x2.shape:
+        return None
+    cot = torch.empty_like(x2)
+    loss = torch.empty(1, dtype=torch.float32, device=x2.device)
+    ws, nb = _workspace(_lib.OP_RHS_FORWARD, p.N, p.H, B, 0, X.device)
+    rc = _lib.load().phx_prior_mse(C.byref(p.c), _p(x2), _p(t2), B, _p(cot), _p(loss), _p(ws), nb, _stream_ptr())
+    if rc == 4:
+        return None
+    _check_call(rc)
+    return loss, cot
+
+
 def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps):
     return _lib.PhxSolveOpts(_lib.METHODS[method], control, float(rtol), float(atol), int(t_per_sample),
                              int(t_is_f32), int(max_num_steps))

@@ -3,6 +3,8 @@
 Same constructor, attribute names, parameter shapes, init and `parameters()` order as the reference
 `ODENet`, so a reference training loop (optimizer param groups by attribute, `save`) runs unchanged.
 `forward` / `prior_only_forward` run on the HIP engine through torch.autograd.Functions."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -61,6 +63,30 @@ class _RhsFn(torch.autograd.Function):
         return vjp, None, gws, gbs, gwp, gbp, gwa, gg
 
 
+class _PriorMSEFn(torch.autograd.Function):
+    """loss_prior = mean((prior_only_forward(X) - prior_grad)^2) (train_insilico.py:134-135) as one engine call: the
+    expansion kernel writes the loss cotangent directly, the prediction is never materialised."""
+
+    @staticmethod
+    def forward(ctx, X, target, ws, bs, wp, bp, wa, g):
+        p = engine.Params(ws, bs, wp, bp, wa, g)
+        res = engine.prior_mse(p, X, target)
+        if res is None:
+            raise RuntimeError("phoenix_amd: the fused prior loss is not available for this shape / engine mode")
+        loss, cot = res
+        ctx.save_for_backward(X, cot, ws, bs, wp, bp, wa, g)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        X, cot, ws, bs, wp, bp, wa, g = ctx.saved_tensors
+        p = engine.Params(ws, bs, wp, bp, wa, g)
+        _, grads = engine.rhs_vjp(p, X, cot, True, want_grads=True, want_vjp_y=False)
+        grads.flat.mul_(grad_out)          # the cotangent was formed for d loss = 1
+        gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)
+        return None, None, gws, gbs, gwp, gbp, gwa, gg
+
+
 class ODENet(nn.Module):
     """ODE-Net (reference odenet.py:38-98)."""
 
@@ -89,6 +115,18 @@ class ODENet(nn.Module):
     def prior_only_forward(self, t, y):
         """odenet.py:93-98"""
         return _RhsFn.apply(y, True, *params_of(self))
+
+    def prior_mse(self, t, batch_for_prior, prior_grad):
+        """`torch.mean((self.prior_only_forward(t, batch_for_prior) - prior_grad) ** 2)` (train_insilico.py:134-135);
+        fused on the engine for large batches whose input needs no gradient, the plain formula otherwise."""
+        fused_ok = (batch_for_prior.is_cuda and not batch_for_prior.requires_grad and not prior_grad.requires_grad and
+                    batch_for_prior.shape == prior_grad.shape and
+                    batch_for_prior.numel() // self.ndim >= engine.PRIOR_MSE_MIN_ROWS and
+                    self.net_sums.linear_out.weight.shape[0] <= 256 and
+                    os.environ.get("PHX_ENGINE") != "v0" and os.environ.get("PHX_PGRAD") != "v1")
+        if fused_ok:
+            return _PriorMSEFn.apply(batch_for_prior, prior_grad, *params_of(self))
+        return torch.mean((self.prior_only_forward(t, batch_for_prior) - prior_grad) ** 2)
 
     def save(self, fp):
         """four-file pickle of whole modules, as the reference (odenet.py:100-111)"""

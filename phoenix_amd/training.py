@@ -15,8 +15,11 @@ def training_step(odenet, data_handler, opt, method, batch_size, explicit_time, 
     # reference: python loop of odeint(odenet, batch_point, time)[1]; here one launch, per-sample control
     predictions = odeint_adjoint(odenet, batch, t, method=method)[1]
     loss_data = torch.mean((predictions - target) ** 2)
-    pred_grad = odenet.prior_only_forward(t, batch_for_prior)
-    loss_prior = torch.mean((pred_grad - prior_grad) ** 2)
+    if hasattr(odenet, "prior_mse"):     # phoenix_amd.ODENet: fused on the engine (no [K,1,N] prediction tensor)
+        loss_prior = odenet.prior_mse(t, batch_for_prior, prior_grad)
+    else:                                # the reference's own ODENet class
+        pred_grad = odenet.prior_only_forward(t, batch_for_prior)
+        loss_prior = torch.mean((pred_grad - prior_grad) ** 2)
     composed_loss = loss_lambda * loss_data + (1 - loss_lambda) * loss_prior
     composed_loss.backward()
     if grad_sync is not None:

@@ -605,6 +605,17 @@ def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     # full RHS on the same batch (forward kernel, non-prior mode)
     f = net(torch.tensor(0.0), Xt)
     assert relerr(f.detach().cpu().numpy(), oracle.rhs(onet, X)) < TOL_RHS
+    # fused loss head (ODENet.prior_mse, used by training_step): same loss, same gradients
+    zero_grads(net)
+    loss2 = net.prior_mse(torch.tensor(0.0), Xt, tt)
+    assert abs(float(loss2.detach()) - float(loss.detach())) <= 2e-6 * abs(float(loss.detach()))
+    (0.01 * loss2).backward()            # a loss weight like (1 - lambda) must scale the gradients
+    got2 = grads_of(net)
+    for k in KEYS:
+        if np.max(np.abs(gr_ref[k])) == 0:
+            assert np.max(np.abs(got2[k])) == 0, k
+        else:
+            assert relerr(got2[k], 0.01 * gr_ref[k]) < 4 * TOL_RHS, k
 
 
 def test_batches_larger_than_one_residency_are_chunked(pa, dev):
