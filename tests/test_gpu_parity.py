@@ -618,6 +618,28 @@ def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
             assert relerr(got2[k], 0.01 * gr_ref[k]) < 4 * TOL_RHS, k
 
 
+def test_prior_branch_pass_structured_fallback(pa, dev, oracle, monkeypatch):
+    """PHX_PGRAD=v1: the pass-structured k1_eval_pgrad (kept as the fallback of the kernel chain) still agrees."""
+    monkeypatch.setenv("PHX_PGRAD", "v1")
+    N, H, K = 1537, 24, 333
+    p = rand_params(N, H, seed=5, std=0.08)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(2)
+    X = (r.rand(K, 1, N) - 0.5).astype(np.float32)
+    tgt = (r.randn(K, 1, N) * 0.1).astype(np.float32)
+    pred = net.prior_only_forward(torch.tensor(0.0), torch.from_numpy(X).to(dev))
+    ref = oracle.rhs(onet, X, prior_only=True)
+    assert relerr(pred.detach().cpu().numpy(), ref) < TOL_RHS
+    torch.mean((pred - torch.from_numpy(tgt).to(dev)) ** 2).backward()
+    _, gr_ref, _ = oracle.rhs_vjp(onet, X, (2.0 * (ref - tgt) / ref.size).astype(np.float32), prior_only=True)
+    got = grads_of(net)
+    for k in KEYS:
+        if np.max(np.abs(gr_ref[k])) == 0:
+            assert np.max(np.abs(got[k])) == 0, k
+        else:
+            assert relerr(got[k], gr_ref[k]) < 4 * TOL_RHS, k
+
+
 def test_batches_larger_than_one_residency_are_chunked(pa, dev):
     """B = 2000 trajectories at N = 11165 exceed what one persistent launch can hold co-resident; the host then
     walks the batch in chunks (per-trajectory control => trajectories are independent).  Property: every row
