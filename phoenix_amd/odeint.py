@@ -69,10 +69,12 @@ def _t64_of(t, device):
     if c is not None and c[0]() is t and c[1] == (t._version, t.data_ptr(), str(device)):
         return c[2]
     t64 = t.detach().to(device=device, dtype=torch.float64).contiguous()
-    try:
-        _t64_last[0] = (weakref.ref(t), (t._version, t.data_ptr(), str(device)), t64)
-    except TypeError:
-        _t64_last[0] = None
+    _t64_last[0] = None
+    if t.is_cuda:   # host tensors may alias numpy memory that changes without a version bump: never cached
+        try:
+            _t64_last[0] = (weakref.ref(t), (t._version, t.data_ptr(), str(device)), t64)
+        except TypeError:
+            pass
     return t64
 
 
