@@ -15,6 +15,9 @@ def _require_gpu(x, name):
     if not x.is_cuda:
         raise RuntimeError("phoenix_amd: `%s` must live on the GPU (cuda/HIP device); this engine has no CPU path"
                            % name)
+    if x.is_floating_point() and x.dtype != torch.float32:
+        raise TypeError("phoenix_amd: `%s` must be float32 (got %s); the engine computes in float32 like the "
+                        "reference's configs" % (name, x.dtype))
 
 
 def _stream_ptr():
@@ -114,6 +117,7 @@ def rhs_forward(p, y, prior_only=False):
 
 def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True):
     _require_gpu(y, "y")
+    _require_gpu(cot, "cot")
     y2 = y.detach().reshape(-1, p.N).contiguous()
     c2 = cot.detach().reshape(-1, p.N).contiguous()
     B = y2.shape[0]
@@ -132,6 +136,7 @@ def prior_mse(p, X, target):
     """fused mean((prior_only_forward(X) - target)^2) and its cotangent; returns (loss [1], cot like X) or None when
     the engine cannot plan the batch chain for this shape (caller falls back to the unfused formula)."""
     _require_gpu(X, "X")
+    _require_gpu(target, "target")
     x2 = X.detach().reshape(-1, p.N).contiguous()
     t2 = target.detach().reshape(-1, p.N).contiguous()
     B = x2.shape[0]
