@@ -1576,11 +1576,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
                 if (!set_lds(k1_solve_adj<8, 256, true>, lds)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
-            } else if (d1.HT == 3 && d1.NW == 8) {
-                if (!set_lds(k1_solve_adj<3, 512, false>, lds)) return PHX_ERR_LAUNCH;
-                hipLaunchKernelGGL((k1_solve_adj<3, 512, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
-                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
-            } else if (d1.HT == 3) {
+            } else if (d1.HT == 3) {   // NW <= ADJ_NW_CAP = 4 (the kernel's LDS combine layout relies on it)
                 if (!set_lds(k1_solve_adj<3, 256, false>, lds)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<3, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
