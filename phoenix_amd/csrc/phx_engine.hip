@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -1140,11 +1141,18 @@ template <int HT>
 int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
                        char *base, hipStream_t st);
 
+// raises the dynamic-LDS limit of a kernel; the driver call is made only when a launch needs more than any before it
 template <typename K>
 bool set_lds(K kernel, size_t bytes)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes) == hipSuccess;
+    static std::atomic<size_t> granted{0};      // one instance per kernel type K (= per instantiation pointer type)
+    static std::atomic<const void *> owner{nullptr};
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    if (owner.load(std::memory_order_acquire) == fn && granted.load(std::memory_order_acquire) >= bytes) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    owner.store(fn, std::memory_order_release);
+    granted.store(bytes, std::memory_order_release);
+    return true;
 }
 
 template <int HT>

@@ -3,6 +3,7 @@
 PyTorch here is plumbing (device memory, streams, autograd bookkeeping); all arithmetic of the
 path happens in libphoenix_hip.so."""
 import ctypes as C
+import os
 
 import torch
 
@@ -24,8 +25,16 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_ws_bytes = {}
+_PLAN_ENV = ("PHX_ENGINE", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS")
+
+
 def _workspace(op, N, H, B, T, device):
-    nbytes = _lib.load().phx_workspace_bytes(op, N, H, B, T)
+    # the size query re-plans the launch on the host: remembered per shape (and per diagnostic switch setting)
+    key = (op, N, H, B, T) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    nbytes = _ws_bytes.get(key)
+    if nbytes is None:
+        nbytes = _ws_bytes[key] = _lib.load().phx_workspace_bytes(op, N, H, B, T)
     key = (device.index, torch.cuda.current_stream().cuda_stream, op)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
