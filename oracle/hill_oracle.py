@@ -37,3 +37,29 @@ def simulate(names, expressions, x0, times, rtol=1e-10, atol=1e-12):
 
     sol = solve_ivp(f, (times[0], times[-1]), np.asarray(x0, np.float64), t_eval=times, method="LSODA", rtol=rtol, atol=atol)
     return sol.y.T
+
+
+def interpret_programs(code, consts, off, length, x):
+    """fp64 interpreter of the postfix programs phoenix_amd.simulator compiles (same opcodes as csrc/phx_hill.inc):
+    checks the COMPILER against `rhs` above without a GPU."""
+    x = np.asarray(x, np.float64)
+    out = np.zeros_like(x)
+    for g in range(len(off)):
+        st = []
+        for op, arg in code[off[g]: off[g] + length[g]]:
+            if op == 0:
+                st.append(np.full(x.shape[:-1], consts[arg]))
+            elif op == 1:
+                st.append(x[..., arg])
+            elif op == 6:
+                st[-1] = -st[-1]
+            elif op == 7:
+                b, k, n = consts[arg: arg + 3]
+                tn = np.where(st[-1] > 0, np.abs(st[-1]) ** n, 0.0)
+                st[-1] = b * tn / (k + tn)
+            else:
+                r = st.pop()
+                st[-1] = st[-1] + r if op == 2 else st[-1] - r if op == 3 else st[-1] * r if op == 4 else st[-1] / r
+        if st:
+            out[..., g] = st[0]
+    return out

@@ -127,30 +127,6 @@ class HillSystem:
     def from_csv(cls, path, device="cuda"):
         return cls(*read_ode_system(path), device=device)
 
-    # ---- host interpreter of the same programs (fp64): test infrastructure for the compiler, not a compute path
-    def rhs_host(self, x):
-        x = np.asarray(x, np.float64)
-        out = np.zeros_like(x)
-        for g in range(self.N):
-            st = []
-            for op, arg in self.code_host[self.off_host[g]: self.off_host[g] + self.len_host[g]]:
-                if op == 0:
-                    st.append(np.full(x.shape[:-1], self.consts_host[arg]))
-                elif op == 1:
-                    st.append(x[..., arg])
-                elif op == 6:
-                    st[-1] = -st[-1]
-                elif op == 7:
-                    b, k, n = self.consts_host[arg: arg + 3]
-                    tn = np.where(st[-1] > 0, np.abs(st[-1]) ** n, 0.0)
-                    st[-1] = b * tn / (k + tn)
-                else:
-                    r = st.pop()
-                    st[-1] = st[-1] + r if op == 2 else st[-1] - r if op == 3 else st[-1] * r if op == 4 else st[-1] / r
-            if st:
-                out[..., g] = st[0]
-        return out
-
     # ---- device
     def _args(self):
         p = engine._p

@@ -29,7 +29,8 @@ def test_compiled_programs_match_the_expression_strings(tmp_path):
     g = load_golden("g11_hill")
     sys_ = _system(g, "cpu", tmp_path)
     assert sys_.N == 350 and int(sys_.is_input.sum()) == 74          # 74 "input gene" rows in the shipped network
-    got = sys_.rhs_host(g["X"])
+    from oracle import hill_oracle
+    got = hill_oracle.interpret_programs(sys_.code_host, sys_.consts_host, sys_.off_host, sys_.len_host, g["X"])
     assert np.max(np.abs(got - g["rates"])) < 1e-12
     assert np.all(got[:, sys_.is_input] == 0)
 
