@@ -740,3 +740,44 @@ def test_f3_calculate_trajectory(pa, dev):
     got = np.stack([x.numpy() for x in trajs])
     assert got.shape == g["trajectories"].shape
     assert relerr(got, g["trajectories"]) < TOL_DOPRI
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
+    """Seeded fuzz over shapes the planner treats differently (ragged gene blocks, 1..5 trajectory tiles, helper waves,
+    small groups, H <= 48 / <= 128 / chunked, shared and per-trajectory control, every method, several output times):
+    the MFMA engine against the independent VALU engine (PHX_ENGINE=v0), forward solution and all gradients."""
+    import os
+    r = np.random.RandomState(1000 + seed)
+    N = int(r.choice([33, 96, 350, 777, 1500]))
+    H = int(r.choice([5, 24, 40, 64, 120, 150]))
+    B = int(r.choice([1, 3, 17, 40, 70]))
+    method = str(r.choice(["dopri5", "rk4", "midpoint", "euler"]))
+    T = int(r.choice([2, 3, 5]))
+    per_sample = bool(r.rand() < 0.5)
+    p = rand_params(N, H, seed=seed, std=0.6 / np.sqrt(N))
+    net = make_net(pa, dev, p)
+    y0 = (r.rand(B, 1, N) * 1.2 - 0.1).astype(np.float32)
+    tgrid = np.cumsum(np.concatenate([[0.0], r.uniform(0.1, 0.5, T - 1)])).astype(np.float32)
+    if r.rand() < 0.25:
+        tgrid = tgrid[::-1].copy()                       # decreasing time
+    t = np.tile(tgrid, (B, 1)) if per_sample else tgrid
+    G = r.randn(T, B, 1, N).astype(np.float32)
+    res = {}
+    for eng in ("v1", "v0"):
+        if eng == "v0":
+            os.environ["PHX_ENGINE"] = "v0"
+        try:
+            zero_grads(net)
+            y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+            sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
+            (sol * torch.from_numpy(G).to(dev)).sum().backward()
+        finally:
+            os.environ.pop("PHX_ENGINE", None)
+        res[eng] = (sol.detach().cpu().numpy(), y0t.grad.cpu().numpy(), grads_of(net))
+    what = (N, H, B, T, method, per_sample)
+    tol, gtol = (TOL_DOPRI, TOL_DOPRI_GRAD) if method == "dopri5" else (TOL_FIXED, TOL_FIXED)
+    assert relerr(res["v1"][0], res["v0"][0]) < tol, what
+    assert relerr(res["v1"][1], res["v0"][1]) < gtol, what
+    for k in KEYS:
+        assert relerr(res["v1"][2][k], res["v0"][2][k]) < gtol, (k,) + what
