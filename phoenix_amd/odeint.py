@@ -150,7 +150,15 @@ class _OdeintAdjointFn(torch.autograd.Function):
         adj_y0, grads, status, _nfe, _ns = engine.solve_adjoint(
             p, t64, sol, grad_sol.contiguous(), a_method, control, a_rtol, a_atol, per_sample, t_is_f32,
             want_grads=need_p, max_num_steps=max_steps, stats=None if ctx.phx_stats is None else ctx.phx_stats[1])
-        engine.raise_for_status(status if ctx.phx_stats is None else ctx.phx_stats[:, 0])
+        # The status read-back is the one host<->device round trip of a training step.  It is queued as an
+        # end-of-backward callback of the autograd engine (the mechanism DDP finalises with): the exception still comes
+        # out of loss.backward(), but the host returns the gradients and runs its accumulation nodes while the kernel
+        # is still executing instead of after it.
+        stats = status if ctx.phx_stats is None else ctx.phx_stats[:, 0]
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: engine.raise_for_status(stats))
+        except Exception:   # noqa: BLE001  (no running graph task: check right here)
+            engine.raise_for_status(stats)
         if need_p:
             gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)
         else:
