@@ -70,7 +70,8 @@ typedef struct phx_solve_opts {
     int control;        /* phx_control */
     double rtol, atol;  /* odeint defaults 1e-7 / 1e-9 (odeint.py:30) */
     int t_per_sample;   /* 0: t is [T] shared;  1: t is [B, T] (training loop: t[b] = (t_i, t_{i+1})) */
-    int t_is_f32;       /* the caller's t tensor was float32 (fixed-grid dt is then formed in fp32) */
+    int t_is_f32;       /* 1: the caller's t tensor was float32 (fixed-grid dt is then formed in fp32);
+                           2: ... and the buffer passed as `t` still holds float32 values (no conversion) */
     long long max_num_steps; /* <=0: 2^31-1 like the reference (rk_common.py:110) */
 } phx_solve_opts;
 

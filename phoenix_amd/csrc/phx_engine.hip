@@ -46,7 +46,8 @@ struct Dims {
 };
 
 struct SolveCfg {
-    int method, control, t_per_sample, t_is_f32;
+    int method, control, t_per_sample, t_is_f32;   // t_is_f32: 1 = the caller's grid was fp32, 2 = ... and `t` still is
+                                                   // (float data, read as double on the fly: no conversion kernel)
     float rtol, atol;  // the reference multiplies fp32 tensors by these (cast to fp32)
     long long max_steps;
 };
@@ -433,13 +434,25 @@ __global__ void k_reduce_grads(const float *__restrict__ dtheta, int GB, long lo
 // ========================================================================================
 // solver helpers
 // ========================================================================================
-__device__ __forceinline__ const double *trow(const double *t, const Dims &d, const SolveCfg &cfg, int b)
+// one trajectory's row of the time grid; the buffer holds doubles, or floats when cfg.t_is_f32 == 2
+struct TimeRow {
+    const void *p;
+    bool f32;
+    __device__ __forceinline__ double operator[](int i) const
+    {
+        return f32 ? (double)static_cast<const float *>(p)[i] : static_cast<const double *>(p)[i];
+    }
+};
+__device__ __forceinline__ TimeRow trowT(const double *t, int T, const SolveCfg &cfg, int b)
 {
-    return cfg.t_per_sample ? t + (long long)b * d.T : t;
+    const bool f32 = cfg.t_is_f32 == 2;
+    const long long off = cfg.t_per_sample ? (long long)b * T : 0;
+    return TimeRow{f32 ? static_cast<const void *>(reinterpret_cast<const float *>(t) + off)
+                       : static_cast<const void *>(t + off), f32};
 }
-__device__ __forceinline__ const double *trowT(const double *t, int T, const SolveCfg &cfg, int b)
+__device__ __forceinline__ TimeRow trow(const double *t, const Dims &d, const SolveCfg &cfg, int b)
 {
-    return cfg.t_per_sample ? t + (long long)b * T : t;
+    return trowT(t, d.T, cfg, b);
 }
 
 // stage input of the fixed-grid methods, in the reference's own operation order
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 
     // ---- init: controllers + state
     for (long long cb = gtid; cb < d.Bc; cb += gsize) {
-        const double *tb = trow(t, d, cfg, (int)cb);
+        const TimeRow tb = trow(t, d, cfg, (int)cb);
         float sg = 1.0f;
         int st = PHX_OK;
         if (T >= 2) {
@@ -600,7 +613,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
                     if (w.done[cb]) continue;
                     const bool valid = n < d.N;
                     const long long e = (long long)b * d.N + n;
-                    const double *tb = trow(t, d, cfg, b);
+                    const TimeRow tb = trow(t, d, cfg, b);
                     const double sg = (double)w.sgn[cb];
                     const double s0 = sg * tb[i], s1 = sg * tb[i + 1];
                     const float dt = cfg.t_is_f32 ? ((float)s1 - (float)s0) : (float)(s1 - s0);
@@ -626,7 +639,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
                     if (valid) {
                         w.KY[(long long)st * d.BN + e] = w.sgn[cb] * f;
                         if (st == S - 1) {
-                            const double *tb = trow(t, d, cfg, b);
+                            const TimeRow tb = trow(t, d, cfg, b);
                             const double sg = (double)w.sgn[cb];
                             const double s0 = sg * tb[i], s1 = sg * tb[i + 1];
                             const float dt = cfg.t_is_f32 ? ((float)s1 - (float)s0) : (float)(s1 - s0);
@@ -747,7 +760,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
             // ---- controller: accept/reject, next dt, output scheduling (rk_common.py:150-220)
             for (long long cb = gtid; cb < d.Bc; cb += gsize) {
                 if (w.done[cb]) continue;
-                const double *tb = trow(t, d, cfg, (int)cb);
+                const TimeRow tb = trow(t, d, cfg, (int)cb);
                 const double sg = (double)w.sgn[cb];
                 const float ratio = rms_from_sum(ctrl_sum(d, w, (int)cb, shared, 0), cnt);
                 const int acc = (ratio <= 1.0f) ? 1 : 0;
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
                     const double t0 = w.rk_t0[cb], t1 = w.rk_t1[cb];
                     const float dts = w.dtp[cb];
                     const float ym = y0v + dp_combo(DP_CMID, w.KY, d.BN, e, dts);
-                    const double *tb = trow(t, d, cfg, b);
+                    const TimeRow tb = trow(t, d, cfg, b);
                     const double sg = (double)w.sgn[cb];
                     for (int jo = lo; jo < hi; ++jo) {
                         const double x = (sg * tb[jo] - t0) / (t1 - t0);
@@ -1484,7 +1497,9 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
         d1.BN = (long long)B * p->N;   // time stride of the caller's [T,B,N] arrays
         {
             const float *y0 = y0_all + (long long)b0 * p->N;
-            const double *t = o->t_per_sample ? t_all + (long long)b0 * T : t_all;
+            const double *t = !o->t_per_sample ? t_all   // rows of b0 onward; the buffer holds floats when t_is_f32 == 2
+                              : reinterpret_cast<const double *>(reinterpret_cast<const char *>(t_all) +
+                                                                 (size_t)b0 * T * (o->t_is_f32 == 2 ? 4 : 8));
             float *sol = sol_all + (long long)b0 * p->N;
             int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
             const Layout1 L1 = make_layout1(d1, 2 * d1.HT, false);
@@ -1562,7 +1577,9 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
         if (!plan_v1(p->N, p->H, bc, T, o->control, NVEC_ADJ, 4, ADJ_LDS_EXTRA, &d1, 40, ADJ_NW_CAP)) return PHX_ERR_BAD_ARG;
         d1.BN = (long long)B * p->N;
         {
-            const double *t = o->t_per_sample ? t_all + (long long)b0 * T : t_all;
+            const double *t = !o->t_per_sample ? t_all   // rows of b0 onward; the buffer holds floats when t_is_f32 == 2
+                              : reinterpret_cast<const double *>(reinterpret_cast<const char *>(t_all) +
+                                                                 (size_t)b0 * T * (o->t_is_f32 == 2 ? 4 : 8));
             const float *y_saved = y_saved_all + (long long)b0 * p->N, *grad_y = grad_y_all + (long long)b0 * p->N;
             float *adj_y0 = adj_y0_all + (long long)b0 * p->N;
             int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;

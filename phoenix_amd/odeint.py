@@ -65,10 +65,14 @@ def _prepare(func, y0, t, options):
     engine._require_gpu(y0, "y0")
     y2 = y0.reshape(-1, N)
     B = y2.shape[0]
-    t_is_f32 = t.dtype == torch.float32
     if t.device != y0.device:
         warnings.warn("t is not on the same device as y0. Coercing to y0.device.")   # misc.py:232-235
-    t64 = t.detach().to(device=y0.device, dtype=torch.float64).contiguous()
+    if t.dtype == torch.float32:     # the engine reads a float32 grid as it is (time arithmetic stays fp64 inside)
+        t_is_f32 = 2
+        t64 = t.detach().to(device=y0.device).contiguous()
+    else:
+        t_is_f32 = 0
+        t64 = t.detach().to(device=y0.device, dtype=torch.float64).contiguous()
     per_sample = t.ndimension() == 2
     if per_sample and t.shape[0] != B:
         raise ValueError("phoenix_amd: per-sample t must be [B, T] with B = %d trajectories" % B)
