@@ -26,15 +26,20 @@ def allreduce_grads(module, scale=None):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if scale is not None:
         flat.mul_(scale)
-    off = 0
+    views, off = [], 0
     for p in ps:
         n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        views.append(flat[off:off + n].view_as(p))
         off += n
+    have = [p.grad is not None for p in ps]
+    if all(have):
+        torch._foreach_copy_([p.grad for p in ps], views)     # one fused copy-back instead of one kernel per tensor
+    else:
+        for p, g in zip(ps, views):
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
 
 
 def allreduce_scalars(*vals):
