@@ -1,13 +1,28 @@
-"""Builds libphoenix_hip.so (the C-ABI engine, include/phoenix_hip.h) in-tree with hipcc for gfx950."""
+"""Builds libphoenix_hip.so (the C-ABI engine, include/phoenix_hip.h) in-tree with hipcc for gfx950.
+
+Every `.hip` file under csrc/ is one translation unit; they are compiled in parallel into csrc/_obj/ and linked
+into one shared library.  A unit is recompiled when it, any `.inc` / `.hpp` under csrc/ or the public header is
+newer than its object (the units include each other's pieces, so dependencies are tracked per directory)."""
+import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libphoenix_hip.so")
-SOURCES = ["phx_engine.hip"]
-DEPS = ["phx_engine.hip", "phx_adjoint.inc", "phx_device.hpp", os.path.join(ROOT, "include", "phoenix_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def deps():
+    """every file a translation unit may include"""
+    return sorted(glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "*.hpp")) +
+                  [os.path.join(ROOT, "include", "phoenix_hip.h")])
 
 
 def hipcc():
@@ -17,22 +32,40 @@ def hipcc():
     return "hipcc"
 
 
+def _obj_of(src):
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(src):
+    o = _obj_of(src)
+    if not os.path.exists(o):
+        return True
+    ot = os.path.getmtime(o)
+    return any(os.path.getmtime(p) > ot for p in [src] + deps())
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     lt = os.path.getmtime(LIB)
-    for d in DEPS:
-        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.getmtime(p) > lt:
-            return True
-    return False
+    return any(_stale(s) or os.path.getmtime(_obj_of(s)) > lt for s in sources())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [s for s in sources() if force or _stale(s)]
+    procs = []
+    for s in todo:
+        cmd = [hipcc()] + FLAGS + ["-c", s, "-o", _obj_of(s)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj_of(s) for s in sources()]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -40,4 +73,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -22,17 +22,13 @@
 #include <cstring>
 #include <cstdlib>
 
-#include "../../include/phoenix_hip.h"
-#include "phx_device.hpp"
+#include "phx_solver.hpp"
+#include "phx_host.hpp"
 
-using namespace phx;
+using namespace phxh;
 
 namespace {
 
-struct Net {
-    const float *Ws, *bs, *Wp, *bp, *WaT, *g;
-    int N, H;
-};
 
 struct Dims {
     int N, H, B, T;
@@ -45,12 +41,6 @@ struct Dims {
     long long PP;  // padded size of one parameter-gradient partial
 };
 
-struct SolveCfg {
-    int method, control, t_per_sample, t_is_f32;   // t_is_f32: 1 = the caller's grid was fp32, 2 = ... and `t` still is
-                                                   // (float data, read as double on the fly: no conversion kernel)
-    float rtol, atol;  // the reference multiplies fp32 tensors by these (cast to fp32)
-    long long max_steps;
-};
 
 // workspace views (device pointers)
 struct WS {
@@ -73,7 +63,6 @@ struct Layout {
         partial, red, Z, DZ, dtheta;
 };
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline Dims make_dims(int N, int H, int B, int T, int control)
 {
@@ -395,61 +384,9 @@ __global__ __launch_bounds__(NT) void k_eval(Net net, Dims d, WS w, const float 
     if (blockIdx.x == 0 && tid == 0 && status) status[0] = gs.aborted ? PHX_ERR_SYNC_TIMEOUT : PHX_OK;
 }
 
-// grads += sum over trajectory groups of the partials (fixed order => deterministic)
-__global__ void k_reduce_grads(const float *__restrict__ dtheta, int GB, long long PP, int N, int H, float *gWs,
-                               float *gWp, float *gWaT, float *gg, float *gbs, float *gbp)
-{
-    const long long HN = (long long)H * N;
-    const long long total = 4 * HN + N + 2 * H;
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
-    // bulk: the three weight sections, four elements per thread with 16-byte loads when the section size allows
-    // (partials are PP-strided with PP a multiple of 4 and 256-byte aligned bases)
-    const bool vec = (HN & 3) == 0 && (PP & 3) == 0 && (reinterpret_cast<size_t>(dtheta) & 15) == 0 &&
-                     ((reinterpret_cast<size_t>(gWs) | reinterpret_cast<size_t>(gWp) |
-                                         reinterpret_cast<size_t>(gWaT)) & 15) == 0;
-    const long long bulk = vec ? 4 * HN : 0;
-    for (long long e = 4 * tid; e < bulk; e += 4 * nth) {
-        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int g = 0; g < GB; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(dtheta + (long long)g * PP + e);
-            sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
-        }
-        float *dst = (e < HN) ? gWs + e : (e < 2 * HN) ? gWp + (e - HN) : gWaT + (e - 2 * HN);
-        float4 o = *reinterpret_cast<float4 *>(dst);
-        o.x += sacc.x; o.y += sacc.y; o.z += sacc.z; o.w += sacc.w;
-        *reinterpret_cast<float4 *>(dst) = o;
-    }
-    for (long long e = bulk + tid; e < total; e += nth) {
-        float sacc = 0.f;
-        for (int g = 0; g < GB; ++g) sacc += dtheta[(long long)g * PP + e];
-        if (e < HN) gWs[e] += sacc;
-        else if (e < 2 * HN) gWp[e - HN] += sacc;
-        else if (e < 4 * HN) gWaT[e - 2 * HN] += sacc;
-        else if (e < 4 * HN + N) gg[e - 4 * HN] += sacc;
-        else if (e < 4 * HN + N + H) gbs[e - 4 * HN - N] += sacc;
-        else gbp[e - 4 * HN - N - H] += sacc;
-    }
-}
-
 // ========================================================================================
 // solver helpers
 // ========================================================================================
-// one trajectory's row of the time grid; the buffer holds doubles, or floats when cfg.t_is_f32 == 2
-struct TimeRow {
-    const void *p;
-    bool f32;
-    __device__ __forceinline__ double operator[](int i) const
-    {
-        return f32 ? (double)static_cast<const float *>(p)[i] : static_cast<const double *>(p)[i];
-    }
-};
-__device__ __forceinline__ TimeRow trowT(const double *t, int T, const SolveCfg &cfg, int b)
-{
-    const bool f32 = cfg.t_is_f32 == 2;
-    const long long off = cfg.t_per_sample ? (long long)b * T : 0;
-    return TimeRow{f32 ? static_cast<const void *>(reinterpret_cast<const float *>(t) + off)
-                       : static_cast<const void *>(t + off), f32};
-}
 __device__ __forceinline__ TimeRow trow(const double *t, const Dims &d, const SolveCfg &cfg, int b)
 {
     return trowT(t, d.T, cfg, b);
@@ -475,17 +412,6 @@ __device__ __forceinline__ float fixed_final(int method, float y0, const float *
     if (method == PHX_MIDPOINT) return y0 + dt * K[BN + e];
     return y0 + (((K[e] + 3.0f * (K[BN + e] + K[2 * BN + e])) + K[3 * BN + e]) * dt) * 0.125f;
 }
-__device__ __forceinline__ int fixed_nstages(int method)
-{
-    return method == PHX_EULER ? 1 : (method == PHX_MIDPOINT ? 2 : 4);
-}
-// quadrature weight of stage st for the parameter gradient (same combination as fixed_final)
-__device__ __forceinline__ float fixed_weight(int method, int st, float dt)
-{
-    if (method == PHX_EULER) return dt;
-    if (method == PHX_MIDPOINT) return st == 1 ? dt : 0.f;
-    return ((st == 0 || st == 3) ? 1.0f : 3.0f) * dt * 0.125f;
-}
 
 // dopri5 stage input: y0 + k[:st] . (beta_st * dt)   (rk_common.py:64-66), fp32, j ascending
 __device__ __forceinline__ float dp_stage_input(int st, float y0, const float *K, long long BN, long long e,
@@ -503,31 +429,6 @@ __device__ __forceinline__ float dp_combo(const float *coef7, const float *K, lo
     return acc;
 }
 
-// quartic dense output (interp.py:1-47) at fraction x of the step
-struct InterpX { float x1, x2, x3, x4; };
-__device__ __forceinline__ InterpX make_interp_x(double x)
-{
-    InterpX r;
-    double xp = x;
-    r.x1 = (float)x;
-    xp *= x; r.x2 = (float)xp;
-    xp *= x; r.x3 = (float)xp;
-    xp *= x; r.x4 = (float)xp;
-    return r;
-}
-__device__ __forceinline__ float interp_eval(float y0, float y1, float ym, float f0, float f1, float dt,
-                                             const InterpX &ix)
-{
-    const float a = ((2.0f * dt) * (f1 - f0) - 8.0f * (y1 + y0)) + 16.0f * ym;
-    const float bb = ((dt * (5.0f * f0 - 3.0f * f1) + 18.0f * y0) + 14.0f * y1) - 32.0f * ym;
-    const float cc = ((dt * (f1 - 4.0f * f0) - 11.0f * y0) - 5.0f * y1) + 16.0f * ym;
-    const float dd = dt * f0;
-    float total = y0 + ix.x1 * dd;
-    total = total + ix.x2 * cc;
-    total = total + ix.x3 * bb;
-    total = total + ix.x4 * a;
-    return total;
-}
 
 // sum over the items of controller cb (fixed order, fp64) of red[..][slot]
 __device__ __forceinline__ double ctrl_sum(const Dims &d, const WS &w, int cb, bool shared, int slot)
@@ -540,20 +441,6 @@ __device__ __forceinline__ double ctrl_sum(const Dims &d, const WS &w, int cb, b
 
 __device__ __forceinline__ float rms_from_sum(double sum, double count) { return sqrtf((float)(sum / count)); }
 
-// _select_initial_step, first half (misc.py:64-72)
-__device__ __forceinline__ float init_h0(float d0, float d1)
-{
-    if (d0 < 1e-5f || d1 < 1e-5f) return 1e-6f;
-    return (0.01f * d0) / d1;
-}
-// second half (misc.py:77-86), order + 1 = 5
-__device__ __forceinline__ double init_dt(float h0, float d1, float d2)
-{
-    float h1;
-    if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = tmaxf(1e-6f, h0 * 1e-3f);
-    else h1 = powf(0.01f / tmaxf(d1, d2), (float)(1.0 / 5.0));
-    return (double)tminf(100.0f * h0, h1);
-}
 
 // ========================================================================================
 // forward solve:  odeint(ODENet, y0, t)
@@ -869,23 +756,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 // ========================================================================================
 namespace {
 
-int g_num_cus = -1;
-// diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-inline void ev_begin(hipStream_t st) { if (g_ev_start) hipEventRecord(g_ev_start, st); }
-inline void ev_end(hipStream_t st) { if (g_ev_stop) hipEventRecord(g_ev_stop, st); g_ev_start = nullptr; g_ev_stop = nullptr; }
-int num_cus()
-{
-    if (g_num_cus < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        g_num_cus = n;
-    }
-    return g_num_cus;
-}
 
-inline Net to_net(const phx_params *p) { return Net{p->Ws, p->bs, p->Wp, p->bp, p->WaT, p->g, p->N, p->H}; }
 
 inline bool bad_params(const phx_params *p)
 {
@@ -912,15 +783,9 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
 // ---------------------------------------------------------------------------------------------------
 // v1 (MFMA) launch planning
 // ---------------------------------------------------------------------------------------------------
-constexpr size_t LDS_BUDGET = 163840 - 1024;
 constexpr size_t ADJ_LDS_EXTRA = 0;
 constexpr int ADJ_NW_CAP = 4;   // the augmented kernel needs the 512-register budget of one wave per SIMD
 
-bool force_v0()
-{
-    const char *e = getenv("PHX_ENGINE");
-    return e && strcmp(e, "v0") == 0;
-}
 
 // picks (NW, TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency
 bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hidden frag tiles / HT */,
@@ -1026,6 +891,7 @@ W1 make_w1(void *base, const Layout1 &L)
     const char *pe = getenv("PHX_PROF");
     w.prof = (pe && pe[0] == '1') ? (unsigned long long *)(p + L.prof) : nullptr;
     w.wimg = (const float *)(p + L.wimg);
+    w.hq = nullptr;
     return w;
 }
 
@@ -1154,19 +1020,6 @@ template <int HT>
 int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
                        char *base, hipStream_t st);
 
-// raises the dynamic-LDS limit of a kernel; the driver call is made only when a launch needs more than any before it
-template <typename K>
-bool set_lds(K kernel, size_t bytes)
-{
-    static std::atomic<size_t> granted{0};      // one instance per kernel type K (= per instantiation pointer type)
-    static std::atomic<const void *> owner{nullptr};
-    const void *fn = reinterpret_cast<const void *>(kernel);
-    if (owner.load(std::memory_order_acquire) == fn && granted.load(std::memory_order_acquire) >= bytes) return true;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
-    owner.store(fn, std::memory_order_release);
-    granted.store(bytes, std::memory_order_release);
-    return true;
-}
 
 template <int HT>
 int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
@@ -1308,6 +1161,7 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     D1 d1;
     if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
     const bool adj = op == PHX_OP_ADJOINT;
+    if (adj && adj2_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1, adj ? 40 : 0,
                  adj ? ADJ_NW_CAP : 8))
         return PHX_ERR_BAD_ARG;
@@ -1345,6 +1199,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
             if (plan_eval(N, H, B, nbc, &pe)) need = std::max(need, make_layout_eval(pe, true).total);
     }
     if (op == PHX_OP_ADJOINT) {
+        need = std::max(need, adj2_workspace_bytes(N, H, B, T));
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl) {
             const int bc = pick_chunk_v1(N, H, B, T, ctl, true);
@@ -1569,6 +1424,10 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    // second-generation MFMA kernel (wave pairs, fused sweeps): hidden layers that stay LDS resident (phx_adj2.hip)
+    if (adj2_chunk(p->N, p->H, B, T, o->control) > 0)
+        return adj2_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,
+                        workspace, workspace_bytes, st);
     // v1: MFMA kernels (large batches: in chunks; every chunk's partials are added into `grads`)
     const int chunk_a = pick_chunk_v1(p->N, p->H, B, T, o->control, true);
     for (int b0 = 0; chunk_a > 0 && b0 < B; b0 += chunk_a) {

@@ -1,0 +1,104 @@
+// phx_solver.hpp -- types and solver helpers shared by every translation unit of the engine (device + host).
+// Reference citations are on the individual helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/phoenix_hip.h"
+#include "phx_device.hpp"
+
+using namespace phx;
+
+namespace phxt {   // plain types that cross translation units (kernel signatures, host entry points)
+
+struct Net {
+    const float *Ws, *bs, *Wp, *bp, *WaT, *g;
+    int N, H;
+};
+
+struct SolveCfg {
+    int method, control, t_per_sample, t_is_f32;   // t_is_f32: 1 = the caller's grid was fp32, 2 = ... and `t` still is
+                                                   // (float data, read as double on the fly: no conversion kernel)
+    float rtol, atol;  // the reference multiplies fp32 tensors by these (cast to fp32)
+    long long max_steps;
+};
+
+}  // namespace phxt
+using namespace phxt;
+
+namespace {
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// one trajectory's row of the time grid; the buffer holds doubles, or floats when cfg.t_is_f32 == 2
+struct TimeRow {
+    const void *p;
+    bool f32;
+    __device__ __forceinline__ double operator[](int i) const
+    {
+        return f32 ? (double)static_cast<const float *>(p)[i] : static_cast<const double *>(p)[i];
+    }
+};
+__device__ __forceinline__ TimeRow trowT(const double *t, int T, const SolveCfg &cfg, int b)
+{
+    const bool f32 = cfg.t_is_f32 == 2;
+    const long long off = cfg.t_per_sample ? (long long)b * T : 0;
+    return TimeRow{f32 ? static_cast<const void *>(reinterpret_cast<const float *>(t) + off)
+                       : static_cast<const void *>(t + off), f32};
+}
+
+__device__ __forceinline__ int fixed_nstages(int method)
+{
+    return method == PHX_EULER ? 1 : (method == PHX_MIDPOINT ? 2 : 4);
+}
+
+// quadrature weight of stage st for the parameter gradient (same combination as fixed_final)
+__device__ __forceinline__ float fixed_weight(int method, int st, float dt)
+{
+    if (method == PHX_EULER) return dt;
+    if (method == PHX_MIDPOINT) return st == 1 ? dt : 0.f;
+    return ((st == 0 || st == 3) ? 1.0f : 3.0f) * dt * 0.125f;
+}
+
+// quartic dense output (interp.py:1-47) at fraction x of the step
+struct InterpX { float x1, x2, x3, x4; };
+__device__ __forceinline__ InterpX make_interp_x(double x)
+{
+    InterpX r;
+    double xp = x;
+    r.x1 = (float)x;
+    xp *= x; r.x2 = (float)xp;
+    xp *= x; r.x3 = (float)xp;
+    xp *= x; r.x4 = (float)xp;
+    return r;
+}
+__device__ __forceinline__ float interp_eval(float y0, float y1, float ym, float f0, float f1, float dt,
+                                             const InterpX &ix)
+{
+    const float a = ((2.0f * dt) * (f1 - f0) - 8.0f * (y1 + y0)) + 16.0f * ym;
+    const float bb = ((dt * (5.0f * f0 - 3.0f * f1) + 18.0f * y0) + 14.0f * y1) - 32.0f * ym;
+    const float cc = ((dt * (f1 - 4.0f * f0) - 11.0f * y0) - 5.0f * y1) + 16.0f * ym;
+    const float dd = dt * f0;
+    float total = y0 + ix.x1 * dd;
+    total = total + ix.x2 * cc;
+    total = total + ix.x3 * bb;
+    total = total + ix.x4 * a;
+    return total;
+}
+
+// _select_initial_step, first half (misc.py:64-72)
+__device__ __forceinline__ float init_h0(float d0, float d1)
+{
+    if (d0 < 1e-5f || d1 < 1e-5f) return 1e-6f;
+    return (0.01f * d0) / d1;
+}
+
+// second half (misc.py:77-86), order + 1 = 5
+__device__ __forceinline__ double init_dt(float h0, float d1, float d2)
+{
+    float h1;
+    if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = tmaxf(1e-6f, h0 * 1e-3f);
+    else h1 = powf(0.01f / tmaxf(d1, d2), (float)(1.0 / 5.0));
+    return (double)tminf(100.0f * h0, h1);
+}
+
+}  // namespace
