@@ -37,7 +37,7 @@ bool plan_adj2(int N, int H, int B, int T, int control, D1 *out)
         const int slots = NP2 * TPW, TG = (ntt + slots - 1) / slots;
         const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
         if (control == PHX_CTRL_SHARED && TG != 1) continue;
-        const size_t cb = ctl_bytes(Bt) + ADJ2_CTL_EXTRA * Bt;
+        const size_t cb = adj2_ctl_bytes(TPW);
         if (cb + blkbytes > LDS_BUDGET) continue;
         const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
         for (int NB = 1; NB <= NBmax; ++NB) {
@@ -77,10 +77,12 @@ Layout2 make_layout2(const D1 &d, bool grads)
     Layout2 L;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t R = (size_t)d.ntg * 4 * d.HT * 4 + 2 * (size_t)d.ntg;   // hidden rows + norm rows per group
+    const size_t RH = (size_t)d.ntg * 4 * d.HT * 4;
+    const size_t R = RH + 2 * (size_t)d.ntg;    // partial rows per workgroup: hidden rows + one norm row per tile and side
+    const size_t RZ = RH + 4 * (size_t)d.ntg;   // reduced rows per group: the norm rows are double buffered
     L.cnt = take(4096);
     L.part = take((size_t)d.TG * d.G * R * 64 * 8);
-    L.zbuf = take((size_t)d.TG * R * 64 * 8);
+    L.zbuf = take((size_t)d.TG * RZ * 64 * 8);
     L.xbytes = off - L.part;                                // granule buffers are zeroed before every launch
     L.scratch = take((size_t)d.TG * d.G * NVEC_ADJ2 * d.ntg * d.NB * 512 * 4);
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
@@ -92,7 +94,19 @@ Layout2 make_layout2(const D1 &d, bool grads)
     return L;
 }
 
-size_t lds_bytes_adj2(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ctl_bytes(d.Bt) + ADJ2_CTL_EXTRA * d.Bt; }
+size_t lds_bytes_adj2(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + adj2_ctl_bytes(d.TPW); }
+
+// start delay of the second half of the wave pairs (100 MHz ticks); PHX_STAGGER_US overrides (diagnostic)
+int prof_wave()
+{
+    if (const char *e = getenv("PHX_PROF_WAVE")) return atoi(e) & 7;
+    return 0;
+}
+int stagger_ticks()
+{
+    if (const char *e = getenv("PHX_STAGGER_US")) return std::max(0, atoi(e)) * 100;
+    return 1000;
+}
 
 }  // namespace
 
@@ -175,10 +189,10 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         ev_begin(st);
         if (d1.HT == 3)
             hipLaunchKernelGGL((k1_solve_adj2<3>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP, stagger_ticks(), prof_wave());
         else
             hipLaunchKernelGGL((k1_solve_adj2<8>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP, stagger_ticks(), prof_wave());
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {
