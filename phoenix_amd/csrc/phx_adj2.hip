@@ -22,6 +22,11 @@ bool adj2_disabled()
     const char *e = getenv("PHX_ADJ");
     return force_v0() || (e && strcmp(e, "v1") == 0);
 }
+bool adj2_forced()
+{
+    const char *e = getenv("PHX_ADJ");
+    return e && strcmp(e, "v2") == 0;
+}
 
 // picks (TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency (one workgroup per CU)
 bool plan_adj2(int N, int H, int B, int T, int control, D1 *out)
@@ -33,20 +38,29 @@ bool plan_adj2(int N, int H, int B, int T, int control, D1 *out)
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
+    // NP pairs per workgroup: 2 (four waves, one per SIMD, 512 registers each; a wave alternates between its TPW >= 2
+    // tiles, so one tile's exchange is in flight while the other tile computes) or 4 (eight waves, 256 registers)
+    // Measured on MI355X (profiles/r2_adjoint_variants.txt): wide hidden layers (HT = 8) want the 512-register
+    // form (NP = 2: no spills), narrow ones (HT = 3) the eight-wave form (NP = 4); PHX_ADJ2_NP overrides (diagnostic)
+    int np_only = HT == 8 ? 2 : 4;
+    if (const char *e = getenv("PHX_ADJ2_NP")) np_only = atoi(e);
+    for (int NP = 2; NP <= 4; NP += 2)
     for (int TPW = 1; TPW <= 4; TPW <<= 1) {
-        const int slots = NP2 * TPW, TG = (ntt + slots - 1) / slots;
+        if (np_only && NP != np_only) continue;
+        const int slots = NP * TPW, TG = (ntt + slots - 1) / slots;
         const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
         if (control == PHX_CTRL_SHARED && TG != 1) continue;
-        const size_t cb = adj2_ctl_bytes(TPW);
+        const size_t cb = adj2_ctl_bytes(NP, TPW);
         if (cb + blkbytes > LDS_BUDGET) continue;
         const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
         for (int NB = 1; NB <= NBmax; ++NB) {
             const int G = (nblk + NB - 1) / NB;
             if ((long long)TG * G > cus) continue;
-            const long long cost = (long long)TPW * NB * 1000 + Bt / 4;
+            // per-SIMD MFMA work ~ TPW * NB * (waves per SIMD); at equal work one wave per SIMD with two tiles wins
+            const long long cost = (long long)TPW * NB * (NP / 2) * 1000 + Bt / 4 + (NP == 2 && TPW >= 2 ? 0 : 40);
             if (best_cost < 0 || cost < best_cost) {
                 best_cost = cost;
-                best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = 2 * NP2;
+                best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = 2 * NP;
                 best.TPW = TPW; best.G = G; best.TG = TG; best.nblk = nblk; best.ntg = ntg; best.Bt = Bt;
                 best.nvec = NVEC_ADJ2; best.BN = (long long)B * N; best.HC = 1; best.Hc = H;
             }
@@ -54,6 +68,10 @@ bool plan_adj2(int N, int H, int B, int T, int control, D1 *out)
         }
     }
     if (best_cost < 0) return false;
+    // Narrow hidden layer exchanged among many gene tiles (the breast-cancer shape: H = 40, 59 members per group): the
+    // first-generation kernel (one wave per trajectory tile doing both halves of the augmented state: twice the MFMA
+    // work per gene-block visit) is still the faster one there -- 0.73 against 0.90 ms.  PHX_ADJ=v2 forces this kernel.
+    if (best.HT == 3 && best.G > 32 && !adj2_forced()) return false;
     *out = best;
     return true;
 }
@@ -86,15 +104,15 @@ Layout2 make_layout2(const D1 &d, bool grads)
     L.xbytes = off - L.part;                                // granule buffers are zeroed before every launch
     L.scratch = take((size_t)d.TG * d.G * NVEC_ADJ2 * d.ntg * d.NB * 512 * 4);
     const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
-    L.dtheta = take(grads ? PP * 4 * d.TG * NP2 : 0);
+    L.dtheta = take(grads ? PP * 4 * d.TG * (d.NW / 2) : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
-    L.hq = take(grads ? (size_t)d.TG * d.G * 8 * d.TPW * 7 * 2 * d.HT * 256 * 4 : 0);
+    L.hq = take(grads ? (size_t)d.TG * d.G * d.NW * d.TPW * 7 * 2 * d.HT * 256 * 4 : 0);
     L.total = off;
     return L;
 }
 
-size_t lds_bytes_adj2(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + adj2_ctl_bytes(d.TPW); }
+size_t lds_bytes_adj2(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + adj2_ctl_bytes(d.NW / 2, d.TPW); }
 
 // start delay of the second half of the wave pairs (100 MHz ticks); PHX_STAGGER_US overrides (diagnostic)
 int prof_wave()
@@ -105,7 +123,7 @@ int prof_wave()
 int stagger_ticks()
 {
     if (const char *e = getenv("PHX_STAGGER_US")) return std::max(0, atoi(e)) * 100;
-    return 1000;
+    return 0;
 }
 
 }  // namespace
@@ -172,7 +190,7 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         w1.hq = (float *)(base + L.hq);
         const size_t lds = lds_bytes_adj2(d1);
         const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
-        const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * NP2;   // pairs that own tiles
+        const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * (d1.NW / 2);   // pairs that own tiles
         // counters + granule buffers are contiguous: one fill
         if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
         // the quadrature first-touches every element of every partial (plain stores) when T >= 2
@@ -181,18 +199,20 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
         hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT, 1, p->H,
                            blk_floats_ch(d1.HT, p->H));
-        const void *fn = d1.HT == 3 ? reinterpret_cast<const void *>(k1_solve_adj2<3>)
-                                    : reinterpret_cast<const void *>(k1_solve_adj2<8>);
-        if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
-        // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
-        if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
-        ev_begin(st);
-        if (d1.HT == 3)
-            hipLaunchKernelGGL((k1_solve_adj2<3>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP, stagger_ticks(), prof_wave());
-        else
-            hipLaunchKernelGGL((k1_solve_adj2<8>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP, stagger_ticks(), prof_wave());
+        auto launch = [&](auto kern) -> int {
+            const void *fn = reinterpret_cast<const void *>(kern);
+            if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
+            // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
+            if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
+            ev_begin(st);
+            hipLaunchKernelGGL(kern, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y, adj_y0, status, nfe,
+                               nsteps, grads ? 1 : 0, PP, stagger_ticks(), prof_wave());
+            return PHX_OK;
+        };
+        int lrc;
+        if (d1.HT == 3) lrc = d1.NW == 8 ? launch(k1_solve_adj2<3, 4>) : launch(k1_solve_adj2<3, 2>);
+        else lrc = d1.NW == 8 ? launch(k1_solve_adj2<8, 4>) : launch(k1_solve_adj2<8, 2>);
+        if (lrc != PHX_OK) return lrc;
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {

@@ -465,13 +465,19 @@ def test_full_size_bcell_properties(pa, dev, oracle):
 
 
 # --------------------------------------------------------------------------- engine variants
-@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2"])
+@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4"])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
 def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant, method):
-    """The v0 (VALU, grid-barrier) kernels remain the fallback for shapes the v1 (MFMA) plan rejects, and v1
-    has several workgroup geometries: every variant must pass the same oracle check."""
+    """The v0 (VALU, grid-barrier) kernels remain the fallback for shapes the v1 (MFMA) plan rejects, v1 has several
+    workgroup geometries, and the backward solve has two generations of kernels (the second in a four- and an
+    eight-wave form) chosen by shape: every variant must pass the same oracle check."""
     if variant == "v0":
         monkeypatch.setenv("PHX_ENGINE", "v0")
+    elif variant == "adj1":
+        monkeypatch.setenv("PHX_ADJ", "v1")
+    elif variant.startswith("adj2"):
+        monkeypatch.setenv("PHX_ADJ", "v2")
+        monkeypatch.setenv("PHX_ADJ2_NP", variant[-1])
     else:
         monkeypatch.setenv("PHX_V1_MAXNW", variant[-1])
     N, H, B = 777, 12, 21
@@ -764,20 +770,26 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
     t = np.tile(tgrid, (B, 1)) if per_sample else tgrid
     G = r.randn(T, B, 1, N).astype(np.float32)
     res = {}
-    for eng in ("v1", "v0"):
+    # "alt": the backward-kernel generation / geometry the planner would NOT pick for this shape
+    alt = [{"PHX_ADJ": "v2", "PHX_ADJ2_NP": "2"}, {"PHX_ADJ": "v2", "PHX_ADJ2_NP": "4"}, {"PHX_ADJ": "v1"}][seed % 3]
+    for eng in ("v1", "v0", "alt"):
         if eng == "v0":
             os.environ["PHX_ENGINE"] = "v0"
+        if eng == "alt":
+            os.environ.update(alt)
         try:
             zero_grads(net)
             y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
             sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
             (sol * torch.from_numpy(G).to(dev)).sum().backward()
         finally:
-            os.environ.pop("PHX_ENGINE", None)
+            for k in ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP"):
+                os.environ.pop(k, None)
         res[eng] = (sol.detach().cpu().numpy(), y0t.grad.cpu().numpy(), grads_of(net))
     what = (N, H, B, T, method, per_sample)
     tol, gtol = (TOL_DOPRI, TOL_DOPRI_GRAD) if method == "dopri5" else (TOL_FIXED, TOL_FIXED)
-    assert relerr(res["v1"][0], res["v0"][0]) < tol, what
-    assert relerr(res["v1"][1], res["v0"][1]) < gtol, what
-    for k in KEYS:
-        assert relerr(res["v1"][2][k], res["v0"][2][k]) < gtol, (k,) + what
+    for eng in ("v1", "alt"):
+        assert relerr(res[eng][0], res["v0"][0]) < tol, (eng,) + what
+        assert relerr(res[eng][1], res["v0"][1]) < gtol, (eng,) + what
+        for k in KEYS:
+            assert relerr(res[eng][2][k], res["v0"][2][k]) < gtol, (eng, k) + what
