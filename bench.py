@@ -7,7 +7,9 @@ One "step" = one pass of the hot path over one batch of synthetic trajectories:
   + (N GPUs > 1) one flat RCCL all-reduce of the P = 4HN+2H+N gradient floats.
 Default workload = BASELINE.json config C4 (the one the north-star target is quoted on):
 breast-cancer scale N=11165 genes, H=40, 256 trajectory intervals per GPU, dopri5 rtol 1e-7 / atol 1e-9.
-Weak scaling: every rank integrates its own 256 trajectories (no data-path collective).
+Default = weak scaling: every rank integrates its own 256 trajectories (no data-path collective).
+`--scaling strong`: the 256 trajectories of the workload are sharded over the ranks (BASELINE.json config 4:
+"256 trajectory batch sharded 1/2/4/8"), the loss is normalised by the GLOBAL batch.
 
 Metric: gene x trajectory RHS evaluations per second = sum over samples of (forward NFE + augmented NFE) * N / time.
 Prints ONE JSON line (rank 0).
@@ -72,6 +74,37 @@ def one_step(net, y0, t, G, method, world):
     return sol
 
 
+def cpu_baseline_batched(wl, net, y0, t, G):
+    """BASELINE.md section 3, shape (ii): the PyTorch-CPU formulation as ONE batched call over y0[B,1,N] (shared step
+    control, dense GEMMs on every host core), forward solve + adjoint backward -- oracle/torch_baseline.py, a
+    restatement of the reference pinned against the C oracle.  Whole workload, one warm-up on a quarter of it."""
+    from oracle import torch_baseline as tb
+    P = lambda x: x.detach().cpu()
+    tnet = tb.Net(P(net.net_sums.linear_out.weight), P(net.net_sums.linear_out.bias),
+                  P(net.net_prods.linear_out.weight), P(net.net_prods.linear_out.bias),
+                  P(net.net_alpha_combine.linear_out.weight), P(net.gene_multipliers))
+    N = wl["N"]
+    yc, tc, Gc = P(y0), P(t)[0].double(), P(G)
+    B = yc.shape[0]
+
+    def run(nb):
+        t0 = time.perf_counter()
+        sol, nf = tb.odeint(tnet, yc[:nb], tc)
+        t1 = time.perf_counter()
+        _, _, nb_aug = tb.adjoint_backward(tnet, tc, sol, Gc[:, :nb])
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, nf, nb_aug
+
+    run(max(1, B // 4))
+    tf, tbw, nf, nba = run(B)
+    return {"value": (nf + nba) * B * N / (tf + tbw), "unit": "gene*trajectory RHS evals/s",
+            "cores": os.cpu_count() or 1, "torch_threads": torch.get_num_threads(), "kind": "port",
+            "formulation": "one batched odeint_adjoint call (PyTorch CPU, shared step control)",
+            "sample": "%d of %d trajectories, forward %.2f s + adjoint %.2f s" % (B, B, tf, tbw),
+            "forward_evals_per_s": nf * B * N / tf, "augmented_evals_per_s": nba * B * N / tbw,
+            "nfe_forward": int(nf) * B, "nfe_augmented": int(nba) * B}
+
+
 def cpu_baseline(wl, net, y0, t, G, seconds_budget=20.0):
     """The CPU oracle (a port of the reference's algorithm; the Python reference cannot travel to the GPU
     box) on a bounded sample of the same workload, reference-shaped: per-sample loop, theta block in the
@@ -106,6 +139,7 @@ def cpu_baseline(wl, net, y0, t, G, seconds_budget=20.0):
         dt, nf, nb = run(nsamp2)
         nsamp = nsamp2
     return {"value": (nf + nb) * N / dt, "unit": "gene*trajectory RHS evals/s", "cores": cores, "kind": "port",
+            "formulation": "per-sample loop (reference semantics), C port, OpenMP over samples",
             "sample": "%d of %d trajectories, forward + adjoint, per-sample loop, %.1f s" % (nsamp, y.shape[0], dt),
             "nfe_forward": int(nf), "nfe_augmented": int(nb)}
 
@@ -144,6 +178,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="breast", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--status", default="deferred", choices=["deferred", "immediate"],
+                    help="solver status read-back: behind the backward kernel (checked at a later engine call) or a "
+                         "blocking round trip at the end of every backward()")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,16 +200,27 @@ def main():
     import phoenix_amd  # noqa: F401  (fails loudly if the HIP library is missing)
     from phoenix_amd import engine
 
+    engine.set_status_mode(args.status)
     wl = WORKLOADS[args.workload]
     N, H, B = wl["N"], wl["H"], wl["B"]
-    net, y0, t = make_problem(wl, device, seed=rank)          # every rank its own trajectories
+    B_global = B * world
+    if args.scaling == "strong":
+        # the SAME 256-trajectory problem at every world size, sharded over the ranks (contiguous chunks)
+        from phoenix_amd import parallel
+        net, y0, t = make_problem(wl, device, seed=0)
+        lo, hi = parallel.shard_range(B, rank, world)
+        y0, t = y0[lo:hi].contiguous(), t[lo:hi].contiguous()
+        B_global, B = B, hi - lo
+    else:
+        net, y0, t = make_problem(wl, device, seed=rank)      # every rank its own trajectories
     if use_dist:   # replicas share parameters
         import torch.distributed as dist
         for p in net.parameters():
             dist.broadcast(p.data, 0)
     T = t.shape[1]
     gg = torch.Generator(device="cpu").manual_seed(100 + rank)
-    G = (torch.randn(T, B, 1, N, generator=gg) / (B * N)).to(device)   # cotangent of a mean-type loss
+    # cotangent of a mean-type loss over the GLOBAL batch (reference torch.mean over the whole batch, train_insilico.py:132)
+    G = (torch.randn(T, B, 1, N, generator=gg) / (B_global * N)).to(device)
     G[0].zero_()
 
     def sync_all():
@@ -186,8 +235,10 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
+    engine.check_pending_status(wait=True)       # every solve of the timed region is checked inside it
     sync_all()
     elapsed = time.perf_counter() - t_start
+    engine.set_status_mode("immediate")
     if use_dist:
         import torch.distributed as dist
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -246,8 +297,10 @@ def main():
         # w.r.t. y + VJP w.r.t. the parameters).
         flop_fwd = (nfe_fwd / B) * 8.0 * B * N * H
         flop_adj = (nfe_aug / B) * 24.0 * B * N * H
-        dom = "k1_solve_adj" if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"   # key into the PMC summary
-        alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == "k1_solve_adj" else (alg_fwd, flop_fwd, fwd_ms_avg)
+        adj_kernel = {0: "k_solve_adj", 1: "k1_solve_adj", 2: "k1_solve_adj2"}[
+            _lib.load().phx_debug_adjoint_kernel(N, H, B, T, _lib.CTRL_PER_TRAJECTORY)]
+        dom = adj_kernel if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"   # key into the PMC summary
+        alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == adj_kernel else (alg_fwd, flop_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
         # Which roof binds: arithmetic intensity of the algorithmic figures against the fp32 ridge of the part
         # (157.3 TFLOP/s f32-input MFMA / 8 TB/s HBM = 19.7 flop/B, MI355X_MICROARCH.md); SURVEY 8d: C4 at B = 256
@@ -258,7 +311,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streams)
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r1_%s_pmc_hbm.json" % args.workload)
+        pmc_file = os.path.join(ROOT, "profiles", "r2_%s_pmc_hbm.json" % args.workload)
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
@@ -276,7 +329,7 @@ def main():
                                  "frac": tflops / PEAK_MFMA_F32, "algorithmic_flop_per_launch": flop},
                     "traffic": traffic,
                     "measured_hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
-                    "traffic_source": "profiles/r1_%s_pmc_hbm.json (2*FETCH_SIZE + WRITE_SIZE)" % args.workload
+                    "traffic_source": "profiles/r2_%s_pmc_hbm.json (2*FETCH_SIZE + WRITE_SIZE)" % args.workload
                     if traffic else None,
                     "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
                     "forward": {"launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
@@ -286,13 +339,19 @@ def main():
         out = {
             "metric": "ODE-RHS evals/sec (genes x trajectories)", "value": value,
             "unit": "gene*trajectory RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "genes": N, "hidden": H, "trajectories_per_gpu": B,
                        "method": wl["method"], "rtol": 1e-7, "atol": 1e-9, "time_points": wl["t"],
                        "parallelism": "trajectory-sharded x%d, flat gradient all-reduce" % world,
-                       "nfe_forward_per_step": nfe_fwd, "nfe_augmented_per_step": nfe_aug},
+                       "nfe_forward_per_step": nfe_fwd, "nfe_augmented_per_step": nfe_aug,
+                       "status_readback": args.status},
             "roofline": roofline,
+            # forward and augmented evaluations are different units of work: their own rates, from the
+            # launch durations of the two solve kernels on this rank
+            "rates": {"forward_evals_per_s": nfe_fwd * N / (fwd_ms_avg * 1e-3),
+                      "augmented_evals_per_s": nfe_aug * N / (adj_ms_avg * 1e-3),
+                      "kernel_ms_per_step": fwd_ms_avg + adj_ms_avg},
         }
         if world == 1:
             # informational: the reference's full training_step (train_insilico.py:124-140) with its K = 10 000-row
@@ -303,7 +362,15 @@ def main():
                 out["training_step_ms"] = None
                 out["training_step_error"] = repr(exc)[:200]
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(wl, net, y0, t, G)
+            # both shapes BASELINE.md section 3 names; speed-ups are quoted against the stronger one
+            loop = cpu_baseline(wl, net, y0, t, G)
+            try:
+                batched = cpu_baseline_batched(wl, net, y0, t, G)
+            except Exception as exc:   # noqa: BLE001
+                batched = {"value": 0.0, "error": repr(exc)[:200]}
+            cb = dict(batched if batched["value"] >= loop["value"] else loop)
+            cb["per_sample_loop"] = loop
+            cb["batched"] = batched
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
         print(json.dumps(out))

@@ -153,6 +153,10 @@ int phx_hill_simulate(const int *code, const int *off, const int *len, const flo
 void phx_debug_set_kernel_events(void *ev_start, void *ev_stop);
 int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset,
                              int *n_workgroups, int *plan);
+/* Diagnostic only: which backward-solve kernel phx_odeint_adjoint_backward launches for this shape:
+ * 0 = k_solve_adj (VALU, grid barriers), 1 = k1_solve_adj (MFMA, one wave per trajectory tile),
+ * 2 = k1_solve_adj2 (MFMA, wave pairs, fused sweeps).  bench.py keys its profile lookups with it. */
+int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control);
 
 #ifdef __cplusplus
 }

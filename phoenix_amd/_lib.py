@@ -25,7 +25,7 @@ class PhxSolveOpts(C.Structure):
 
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
-           "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse")
+           "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -72,6 +72,7 @@ def load():
     lib.phx_hill_simulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, C.c_int, vp]
     lib.phx_debug_set_kernel_events.argtypes = [vp, vp]
     lib.phx_debug_set_kernel_events.restype = None
+    lib.phx_debug_adjoint_kernel.argtypes = [C.c_int] * 5
     assert lib.phx_abi_version() == 1
     _LIB = lib
     return lib

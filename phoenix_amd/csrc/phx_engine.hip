@@ -48,6 +48,7 @@ struct WS {
     double *rk_t0, *rk_t1, *dt, *xfin;
     float *h0f, *dtf, *dtp, *sgn, *wq;  // dtp: fp32 dt of the step just taken; wq: [B][8] quadrature weights
     int *out_idx, *done, *accept, *out_lo, *out_hi, *fin, *st, *nsteps, *nfe;
+    int *nsiv;                    // steps taken towards the current output time (the reference's per-_advance budget)
     float *Y0, *A0, *YS, *AS;     // [B,N] each
     float *KY, *KA;               // [S][B,N]
     float *SA, *SL, *SQ, *SG;     // [S][B,N] stage data for the parameter-gradient pass
@@ -94,7 +95,7 @@ inline Layout make_layout(const Dims &d, int op)
     L.sync = take(sizeof(SyncBlock));
     L.rk_t0 = take(8 * B); L.rk_t1 = take(8 * B); L.dt = take(8 * B); L.xfin = take(8 * B);
     L.h0f = take(4 * B); L.dtf = take(4 * B); L.dtp = take(4 * B); L.sgn = take(4 * B); L.wq = take(4 * B * 8);
-    L.ints = take(4 * B * 9);
+    L.ints = take(4 * B * 10);
     L.Y0 = take(solve ? 4 * BN : 0);
     L.YS = take(solve ? 4 * BN : 0);
     L.A0 = take(op == PHX_OP_ADJOINT ? 4 * BN : 0);
@@ -124,7 +125,7 @@ inline WS make_ws(void *base, const Layout &L, const Dims &d)
     int *ib = (int *)(p + L.ints);
     const size_t B = d.B;
     w.out_idx = ib; w.done = ib + B; w.accept = ib + 2 * B; w.out_lo = ib + 3 * B; w.out_hi = ib + 4 * B;
-    w.fin = ib + 5 * B; w.st = ib + 6 * B; w.nsteps = ib + 7 * B; w.nfe = ib + 8 * B;
+    w.fin = ib + 5 * B; w.st = ib + 6 * B; w.nsteps = ib + 7 * B; w.nfe = ib + 8 * B; w.nsiv = ib + 9 * B;
     w.Y0 = (float *)(p + L.Y0); w.A0 = (float *)(p + L.A0); w.YS = (float *)(p + L.YS); w.AS = (float *)(p + L.AS);
     w.KY = (float *)(p + L.KY); w.KA = (float *)(p + L.KA);
     w.SA = (float *)(p + L.SA); w.SL = (float *)(p + L.SL); w.SQ = (float *)(p + L.SQ); w.SG = (float *)(p + L.SG);
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
         w.sgn[cb] = sg;
         w.st[cb] = st;
         w.nsteps[cb] = 0;
+        w.nsiv[cb] = 0;
         w.nfe[cb] = 0;
         w.rk_t0[cb] = (double)sg * tb[0];
         w.rk_t1[cb] = (double)sg * tb[0];
@@ -670,12 +672,16 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
                 w.dtp[cb] = w.dtf[cb];
                 w.dt[cb] = dtn;
                 w.dtf[cb] = (float)dtn;
+                // max_num_steps is a budget per output time (n_steps restarts in every _advance, rk_common.py:152-156)
+                // and is tested before the step-size assert of the next step (rk_common.py:154,175)
+                const int nsi = (oi > w.out_lo[cb]) ? 0 : w.nsiv[cb] + 1;
+                w.nsiv[cb] = nsi;
                 int dn = 0;
                 if (oi >= T) dn = 1;
                 else {
                     const double tn = w.rk_t1[cb];
-                    if (!(tn + dtn > tn)) { w.st[cb] = PHX_ERR_DT_UNDERFLOW; dn = 1; }
-                    else if ((long long)ns >= cfg.max_steps) { w.st[cb] = PHX_ERR_MAX_STEPS; dn = 1; }
+                    if ((long long)nsi >= cfg.max_steps) { w.st[cb] = PHX_ERR_MAX_STEPS; dn = 1; }
+                    else if (!(tn + dtn > tn)) { w.st[cb] = PHX_ERR_DT_UNDERFLOW; dn = 1; }
                 }
                 if (dn) {
                     w.fin[cb] = 1;  // finish after this step's accept pass
@@ -1170,6 +1176,12 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     *n_workgroups = d1.TG * d1.G;
     if (plan) { plan[0] = d1.NW; plan[1] = d1.TPW; plan[2] = d1.NB; plan[3] = d1.G; plan[4] = d1.TG; plan[5] = d1.HT; }
     return PHX_OK;
+}
+
+int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control)
+{
+    if (adj2_chunk(N, H, B, T, control) > 0) return 2;
+    return pick_chunk_v1(N, H, B, T, control, true) > 0 ? 1 : 0;
 }
 
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T)

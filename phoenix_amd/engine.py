@@ -71,6 +71,25 @@ class Params:
         return Grads(self)
 
 
+_params_cache = {}
+
+
+def params_cached(Ws, bs, Wp, bp, Wa, g):
+    """`Params` of these six tensors, rebuilt only when one of them changed (storage or in-place version): the engine
+    layout needs a transposed copy of Wa (7 MB at breast scale), which a forward/backward pair, a validation loop or an
+    analysis scan over fixed weights should not redo per call.  An optimizer step bumps the versions."""
+    key = tuple((x.data_ptr(), x._version, tuple(x.shape)) for x in (Ws, bs, Wp, bp, Wa, g))
+    dkey = (Ws.device.index, Ws.data_ptr())
+    hit = _params_cache.get(dkey)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    p = Params(Ws, bs, Wp, bp, Wa, g)
+    if len(_params_cache) > 8:
+        _params_cache.clear()
+    _params_cache[dkey] = (key, p)
+    return p
+
+
 class Grads:
     """One flat zero-initialised buffer carved into the six gradient tensors (the engine accumulates into them);
     `flat` is also what a data-parallel all-reduce wants."""
@@ -102,12 +121,56 @@ def _raise(status, worst):
     raise RuntimeError("phoenix_amd: " + msg)
 
 
+_status_mode = "immediate"
+_pending = []          # (event, pinned status copy [L, B]) of solves whose status has not been read yet
+
+
+def set_status_mode(mode):
+    """"immediate" (default): a training step reads the solver status of its two launches in one blocking round trip at
+    the end of backward(), as the reference raises its asserts synchronously.  "deferred": the status block is copied to
+    pinned host memory behind the backward kernel and checked at a later engine call (or `check_pending_status(True)`)
+    once its event has completed -- the same AssertionError, raised up to two engine calls late, and the host no longer
+    idles the GPU between steps."""
+    global _status_mode
+    assert mode in ("immediate", "deferred")
+    if mode == "immediate":
+        check_pending_status(wait=True)
+    _status_mode = mode
+
+
+def status_mode():
+    return _status_mode
+
+
+def defer_status(status):
+    """queue a device status block [L, B] (or [B]) for a later check"""
+    host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending.append((ev, host))
+
+
+def check_pending_status(wait=False):
+    """raise for every queued solve that has finished (all of them with wait=True)"""
+    while _pending:
+        ev, host = _pending[0]
+        if not wait and not ev.query():
+            return
+        if wait:
+            ev.synchronize()
+        _pending.pop(0)
+        raise_for_status(host)
+
+
 def raise_for_status(status):
     """Maps per-trajectory solver status onto the reference's exceptions (rk_common.py:154,175-176,
     misc.py:114-115).  One device->host read.  `status` is [B], or [L, B] for L consecutive launches (the forward
     and backward solve of a training step share one stats block): the earliest failing launch is reported."""
     if status.dim() == 1:
         status = status.unsqueeze(0)
+    if not status.is_cuda and not bool(status.any()):
+        return
     for launch, worst in enumerate(status.amax(dim=1).tolist()):
         if worst != 0:
             _raise(status[launch], int(worst))

@@ -96,9 +96,9 @@ class _OdeintAdjointFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y2, t64, cfg, ws, bs, wp, bp, wa, g):
-        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj) = cfg
-        p = engine.Params(ws, bs, wp, bp, wa, g)
-        defer = any(ctx.needs_input_grad)
+        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj, defer) = cfg
+        engine.check_pending_status()
+        p = engine.params_cached(ws, bs, wp, bp, wa, g)
         # one zeroed stats block for both launches of the step: [0] forward, [1] backward; rows status/nfe/nsteps
         stats = torch.zeros((2 if defer else 1, 3, y2.shape[0]), dtype=torch.int32, device=y2.device)
         sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol,
@@ -124,11 +124,11 @@ class _OdeintAdjointFn(torch.autograd.Function):
         t64, sol, ws, bs, wp, bp, wa, g = ctx.saved_tensors
         if grad_sol is None:
             grad_sol = torch.zeros_like(sol)
-        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj) = ctx.cfg
+        (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj, _defer) = ctx.cfg
         a_method, a_rtol, a_atol = adj
         p = ctx.phx_params
         if ctx.phx_versions != tuple(x._version for x in (ws, bs, wp, bp, wa, g)):
-            p = engine.Params(ws, bs, wp, bp, wa, g)   # parameters were modified in place since forward
+            p = engine.params_cached(ws, bs, wp, bp, wa, g)   # parameters were modified in place since forward
         need_p = any(ctx.needs_input_grad[3:])
         adj_y0, grads, status, _nfe, _ns = engine.solve_adjoint(
             p, t64, sol, grad_sol.contiguous(), a_method, control, a_rtol, a_atol, per_sample, t_is_f32,
@@ -138,10 +138,13 @@ class _OdeintAdjointFn(torch.autograd.Function):
         # out of loss.backward(), but the host returns the gradients and runs its accumulation nodes while the kernel
         # is still executing instead of after it.
         stats = status if ctx.phx_stats is None else ctx.phx_stats[:, 0]
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: engine.raise_for_status(stats))
-        except Exception:   # noqa: BLE001  (no running graph task: check right here)
-            engine.raise_for_status(stats)
+        if engine.status_mode() == "deferred":
+            engine.defer_status(stats)      # checked at a later engine call, once the kernel has finished
+        else:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: engine.raise_for_status(stats))
+            except Exception:   # noqa: BLE001  (no running graph task: check right here)
+                engine.raise_for_status(stats)
         if need_p:
             gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)
         else:
@@ -154,7 +157,8 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_
     training/validation code always differentiates through `odeint_adjoint` (train_insilico.py:15-18)."""
     y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
-    p = engine.Params(*params)
+    engine.check_pending_status()
+    p = engine.params_cached(*params)
     sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol, atol,
                                                     per_sample, t_is_f32, int(options.get("max_num_steps", 0)))
     engine.raise_for_status(status)
@@ -179,8 +183,12 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     if adjoint_method not in _ENGINE_METHODS:
         raise NotImplementedError("phoenix_amd: adjoint_method '%s' not supported" % adjoint_method)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
+    # The forward status is read together with the backward solve's only when a backward pass can come: autograd must
+    # be recording AND something must require grad (needs_input_grad mirrors .requires_grad even under no_grad: the
+    # reference's validation code calls odeint_adjoint inside torch.no_grad(), train_insilico.py:77-106).
+    defer = torch.is_grad_enabled() and (y0.requires_grad or any(x.requires_grad for x in params))
     cfg = (method, control, rtol, atol, per_sample, t_is_f32, int(options.get("max_num_steps", 0)),
-           (adjoint_method, float(adjoint_rtol), float(adjoint_atol)))
+           (adjoint_method, float(adjoint_rtol), float(adjoint_atol)), defer)
     sol, _nfe = _OdeintAdjointFn.apply(y2, t64, cfg, *params)
     return _out_shape(sol, y0, per_sample)
 

@@ -12,34 +12,31 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def flat_grads(module):
-    ps = [p for p in module.parameters() if p.requires_grad]
-    return ps, torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
-
-
 def allreduce_grads(module, scale=None):
-    """sum-all-reduce every parameter gradient as one flat fp32 buffer; `scale` (e.g. 1/world for a
-    mean loss over the global batch) is applied after the reduction."""
+    """sum-all-reduce every parameter gradient in ONE grouped collective (RCCL group call: no flat copy of the
+    P = 4HN+2H+N floats and no copy back -- the gradients are reduced where autograd left them); `scale` (e.g. 1/world
+    for a mean loss over the global batch) is applied after the reduction."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    ps, flat = flat_grads(module)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if scale is not None:
-        flat.mul_(scale)
-    views, off = [], 0
+    ps = [p for p in module.parameters() if p.requires_grad]
     for p in ps:
-        n = p.numel()
-        views.append(flat[off:off + n].view_as(p))
-        off += n
-    have = [p.grad is not None for p in ps]
-    if all(have):
-        torch._foreach_copy_([p.grad for p in ps], views)     # one fused copy-back instead of one kernel per tensor
-    else:
-        for p, g in zip(ps, views):
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in ps]
+    if not all(g.is_contiguous() for g in grads):
+        for p in ps:
+            p.grad = p.grad.contiguous()
+        grads = [p.grad for p in ps]
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+    except (AttributeError, RuntimeError):   # backend without the grouped form: one collective per tensor
+        for g in grads:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    if scale is not None:
+        torch._foreach_mul_(grads, scale)
 
 
 def allreduce_scalars(*vals):

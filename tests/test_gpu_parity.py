@@ -464,6 +464,87 @@ def test_full_size_bcell_properties(pa, dev, oracle):
         assert relerr(acc[k], full[k]) < 2e-5, k
 
 
+# --------------------------------------------------------------------------- error behaviour of the step budget
+def _stiffish_problem(pa, dev, N=96, H=8, B=3, seed=5):
+    p = rand_params(N, H, seed=seed, std=0.5 / np.sqrt(N))
+    net = make_net(pa, dev, p)
+    y0 = torch.rand(B, 1, N, device=dev)
+    return net, y0
+
+
+def test_forward_failure_raises_under_no_grad(pa, dev):
+    """odeint_adjoint inside torch.no_grad() (the reference's validation code, train_insilico.py:77-106) never gets a
+    backward pass: a failed forward solve must raise right away even though the parameters require grad."""
+    net, y0 = _stiffish_problem(pa, dev)
+    t = torch.tensor([0.0, 3.0], device=dev)
+    with torch.no_grad():
+        with pytest.raises(AssertionError, match="max_num_steps"):
+            pa.odeint_adjoint(net, y0, t, method="dopri5", options={"max_num_steps": 2})
+        pa.odeint_adjoint(net, y0, t, method="dopri5")      # and the unrestricted call still works
+    # grad mode, nothing requires grad: also immediate
+    for q in net.parameters():
+        q.requires_grad_(False)
+    with pytest.raises(AssertionError, match="max_num_steps"):
+        pa.odeint_adjoint(net, y0, t, method="dopri5", options={"max_num_steps": 2})
+
+
+@pytest.mark.parametrize("variant", ["default", "v0", "adj1", "adj2_np2", "adj2_np4"])
+def test_max_num_steps_is_a_budget_per_output_time(pa, dev, monkeypatch, variant):
+    """The reference restarts n_steps in every _advance(next_t) (rk_common.py:152-156) and the adjoint solves interval
+    by interval (adjoint.py:136-154): a budget between the largest per-interval count and the total must pass."""
+    if variant == "v0":
+        monkeypatch.setenv("PHX_ENGINE", "v0")
+    elif variant == "adj1":
+        monkeypatch.setenv("PHX_ADJ", "v1")
+    elif variant.startswith("adj2"):
+        monkeypatch.setenv("PHX_ADJ", "v2")
+        monkeypatch.setenv("PHX_ADJ2_NP", variant[-1])
+    net, y0 = _stiffish_problem(pa, dev)
+    t3 = torch.tensor([0.0, 1.5, 3.0], device=dev)
+    _, _, ns_a = pa.odeint(net, y0, t3[:2], method="dopri5", return_stats=True)
+    _, _, ns_tot = pa.odeint(net, y0, t3, method="dopri5", return_stats=True)
+    n_a, n_tot = int(ns_a.max()), int(ns_tot.max())
+    assert n_tot > n_a + 3, "the fixture should need several steps in each interval"
+    budget = max(n_a, n_tot - n_a) + 2           # enough for either interval, not for both
+    assert budget < n_tot
+    sol = pa.odeint(net, y0, t3, method="dopri5", options={"max_num_steps": budget})
+    assert torch.isfinite(sol).all()
+    # the backward solve restarts its count per interval too (adjoint.py:136-154): its total over both intervals, then a
+    # budget of 80 % of it (the two intervals are roughly balanced)
+    from phoenix_amd import engine, _lib
+    pe = engine.params_cached(*pa.odenet.params_of(net))
+    y2 = y0.reshape(-1, y0.shape[-1]).contiguous()
+    sol, st, _, _ = engine.solve_forward(pe, y2, t3.double(), "dopri5", _lib.CTRL_SHARED, 1e-7, 1e-9, False, 0)
+    Gc = torch.ones_like(sol)
+    _, _, st_b, _, ns_b = engine.solve_adjoint(pe, t3.double(), sol, Gc, "dopri5", _lib.CTRL_SHARED, 1e-7, 1e-9, False, 0)
+    assert int(st.max()) == 0 and int(st_b.max()) == 0
+    nb_tot = int(ns_b.max())
+    _, _, st_b2, _, ns_b2 = engine.solve_adjoint(pe, t3.double(), sol, Gc, "dopri5", _lib.CTRL_SHARED, 1e-7, 1e-9, False, 0,
+                                                 max_num_steps=int(0.8 * nb_tot))
+    assert int(st_b2.max()) == 0 and int(ns_b2.max()) == nb_tot
+    with pytest.raises(AssertionError, match="max_num_steps"):
+        pa.odeint(net, y0, t3, method="dopri5", options={"max_num_steps": min(n_a, n_tot - n_a) - 1})
+
+
+def test_deferred_status_mode(pa, dev):
+    """set_status_mode("deferred"): backward() returns without a device round trip, the same AssertionError comes out
+    of a later engine call / check_pending_status(wait=True)."""
+    net, y0 = _stiffish_problem(pa, dev)
+    t = torch.tensor([0.0, 3.0], device=dev)
+    pa.set_status_mode("deferred")
+    try:
+        y0g = y0.clone().requires_grad_(True)
+        out = pa.odeint_adjoint(net, y0g, t, method="dopri5", options={"max_num_steps": 2})
+        out.sum().backward()                     # no exception here
+        with pytest.raises(AssertionError, match="max_num_steps"):
+            pa.check_pending_status(wait=True)
+        y0g = y0.clone().requires_grad_(True)    # a healthy step leaves nothing behind
+        pa.odeint_adjoint(net, y0g, t, method="dopri5").sum().backward()
+        pa.check_pending_status(wait=True)
+    finally:
+        pa.set_status_mode("immediate")
+
+
 # --------------------------------------------------------------------------- engine variants
 @pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4"])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])

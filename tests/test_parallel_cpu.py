@@ -55,6 +55,101 @@ def test_two_rank_gradient_allreduce_matches_single_process():
         assert abs(tot - float(loss)) < 1e-5 * abs(float(loss))
 
 
+class _StubNet(torch.nn.Module):
+    """CPU stand-in with the two entry points training_step uses (the engine itself is GPU only)"""
+
+    def __init__(self, n):
+        super().__init__()
+        self.lin = torch.nn.Linear(n, n)
+
+    def forward(self, t, y):
+        return torch.tanh(self.lin(y)) - y
+
+    def prior_only_forward(self, t, y):
+        return self.lin(y)
+
+
+def _stub_odeint_adjoint(func, y0, t, method=None):
+    """one explicit Euler step per sample over its own interval: differentiable, deterministic, CPU"""
+    dt = (t[:, 1] - t[:, 0]).reshape(-1, 1, 1)
+    return torch.stack([y0, y0 + dt * func(t[:, 0], y0)])
+
+
+class _Handler:
+    def __init__(self, batch, t, target):
+        self.b = (batch, t, target)
+
+    def get_batch(self, bs):
+        return self.b
+
+
+def _problem():
+    g = torch.Generator().manual_seed(4)
+    B, n, K = 12, 5, 10
+    batch = torch.rand(B, 1, n, generator=g)
+    t = torch.stack([torch.zeros(B), 0.1 + 0.05 * torch.arange(B)], 1)
+    target = torch.rand(B, 1, n, generator=g)
+    X = torch.rand(K, 1, n, generator=g)
+    prior = torch.rand(K, 1, n, generator=g)
+    return B, n, K, batch, t, target, X, prior
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phoenix_amd import parallel, training
+    training.odeint_adjoint = _stub_odeint_adjoint
+    B, n, K, batch, t, target, X, prior = _problem()
+    torch.manual_seed(1)
+    net = _StubNet(n)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    lo, hi = parallel.shard_range(B, rank, world)          # trajectories AND prior rows are sharded the same way
+    klo, khi = parallel.shard_range(K, rank, world)
+    h = _Handler(batch[lo:hi], t[lo:hi], target[lo:hi])
+    # equal shards: the mean over the global batch is the mean of the ranks' means
+    sync = lambda m: parallel.allreduce_grads(m, scale=1.0 / world)   # noqa: E731
+    losses = training.training_step(net, h, opt, "dopri5", hi - lo, False, False, X[klo:khi], prior[klo:khi], 0.7,
+                                    grad_sync=sync)
+    tot = parallel.allreduce_scalars(*losses)
+    q.put((rank, [p.detach().reshape(-1).tolist() for p in net.parameters()], [float(x) / world for x in tot]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_step_matches_single_process():
+    """training_step(..., grad_sync=allreduce_grads) on two ranks, each with half of the trajectories and of the prior
+    batch, takes the same optimizer step as one process with everything (global-batch normalisation of both losses)."""
+    from phoenix_amd import training
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    B, n, K, batch, t, target, X, prior = _problem()
+    torch.manual_seed(1)
+    net = _StubNet(n)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    saved = training.odeint_adjoint
+    training.odeint_adjoint = _stub_odeint_adjoint
+    try:
+        losses = training.training_step(net, _Handler(batch, t, target), opt, "dopri5", B, False, False, X, prior, 0.7)
+    finally:
+        training.odeint_adjoint = saved
+    ref = [p.detach().reshape(-1) for p in net.parameters()]
+    for _, params, tot in res:
+        for a, b in zip(params, ref):
+            assert torch.allclose(torch.tensor(a), b, rtol=1e-5, atol=1e-6)
+        assert abs(tot[0] - float(losses[0])) < 1e-5 and abs(tot[1] - float(losses[1])) < 1e-5
+
+
 def test_shard_range_covers_everything():
     from phoenix_amd.parallel import shard_range
     for n in (1, 7, 256, 1023):
