@@ -1250,11 +1250,11 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
             if (pe.d.HT == 3) {
-                if (!set_lds(k1_eval_fwd<3, 256>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_fwd<3, 256>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_fwd<3, 256>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, out, prior_only,
                                    pe.npass);
             } else {
-                if (!set_lds(k1_eval_fwd<8, 256>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_fwd<8, 256>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_fwd<8, 256>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, out, prior_only,
                                    pe.npass);
             }
@@ -1267,6 +1267,7 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
     const WS w = make_ws(workspace, L, d);
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (!fits_resident(reinterpret_cast<const void *>(k_eval<false>), NT, 0, grid)) return PHX_ERR_LAUNCH;   // grid barriers inside
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     hipLaunchKernelGGL(k_eval<false>, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, y, (const float *)nullptr, out,
                        (float *)nullptr, prior_only, 0, (int *)nullptr);
@@ -1304,16 +1305,16 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(pe.d.TG * pe.d.G), blk1(64 * pe.d.NW);
             if (pe.d.HT == 3 && nbc3 == 2) {
-                if (!set_lds(k1_eval_pgrad<3, 2>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_pgrad<3, 2>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_pgrad<3, 2>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
             } else if (pe.d.HT == 3 && nbc3 == 3) {
-                if (!set_lds(k1_eval_pgrad<3, 3>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_pgrad<3, 3>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_pgrad<3, 3>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
             } else if (pe.d.HT == 3) {
-                if (!set_lds(k1_eval_pgrad<3, 4>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_pgrad<3, 4>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_pgrad<3, 4>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot, pe.npass, PP);
             } else {
-                if (!set_lds(k1_eval_pgrad<8, EVAL_NBC_HT8>, pe.lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_eval_pgrad<8, EVAL_NBC_HT8>, pe.lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_eval_pgrad<8, EVAL_NBC_HT8>), grid1, blk1, pe.lds, st, to_net(p), pe.d, w1, y, cot,
                                    pe.npass, PP);
             }
@@ -1331,6 +1332,7 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
     const WS w = make_ws(workspace, L, d);
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (!fits_resident(reinterpret_cast<const void *>(k_eval<true>), NT, 0, grid)) return PHX_ERR_LAUNCH;   // grid barriers inside
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (grads && hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess)
         return PHX_ERR_LAUNCH;
@@ -1380,19 +1382,19 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
-                if (!set_lds(k1_solve_fwd<8, 256, true>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_fwd<8, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
                                    sol, status, nfe, nsteps);
             } else if (d1.HT == 3 && d1.NW == 8) {
-                if (!set_lds(k1_solve_fwd<3, 512, false>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_fwd<3, 512, false>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<3, 512, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
                                    sol, status, nfe, nsteps);
             } else if (d1.HT == 3) {
-                if (!set_lds(k1_solve_fwd<3, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_fwd<3, 256, false>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<3, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
                                    sol, status, nfe, nsteps);
             } else {
-                if (!set_lds(k1_solve_fwd<8, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_fwd<8, 256, false>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<8, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
                                    sol, status, nfe, nsteps);
             }
@@ -1411,6 +1413,7 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
     const WS w = make_ws(workspace, L, d);
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (!fits_resident(reinterpret_cast<const void *>(k_solve_fwd), NT, 0, grid)) return PHX_ERR_LAUNCH;   // grid barriers inside
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     ev_begin(st);
     hipLaunchKernelGGL(k_solve_fwd, dim3(grid), dim3(NT), 0, st, to_net(p), d, w, cfg, y0, t, sol, status, nfe,
@@ -1469,15 +1472,15 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
-                if (!set_lds(k1_solve_adj<8, 256, true>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_adj<8, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             } else if (d1.HT == 3) {   // NW <= ADJ_NW_CAP = 4 (the kernel's LDS combine layout relies on it)
-                if (!set_lds(k1_solve_adj<3, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_adj<3, 256, false>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<3, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             } else {
-                if (!set_lds(k1_solve_adj<8, 256, false>, lds)) return PHX_ERR_LAUNCH;
+                if (!set_lds_resident(k1_solve_adj<8, 256, false>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<8, 256, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
             }
@@ -1505,6 +1508,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
     const WS w = make_ws(workspace, L, d);
     const int grid = grid_for(d.items);
     if (grid <= 0) return PHX_ERR_LAUNCH;
+    if (!fits_resident(reinterpret_cast<const void *>(k_solve_adj), NT, 0, grid)) return PHX_ERR_LAUNCH;   // grid barriers inside
     if (hipMemsetAsync(w.sync, 0, sizeof(SyncBlock), st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (hipMemsetAsync(w.dtheta, 0, sizeof(float) * (size_t)d.PP * d.GB, st) != hipSuccess) return PHX_ERR_LAUNCH;
     ev_begin(st);

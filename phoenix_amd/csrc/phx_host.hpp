@@ -72,6 +72,14 @@ inline bool fits_resident(const void *fn, int threads, size_t lds, int grid)
     return (long long)per_cu * num_cus() >= grid;
 }
 
+// persistent kernels: LDS limit + co-residency check in one call (PHX_ERR_LAUNCH instead of a grid that would spin)
+template <typename K>
+inline bool set_lds_resident(K kernel, size_t bytes, int threads, int grid)
+{
+    const void *fn = reinterpret_cast<const void *>(kernel);
+    return set_lds_fn(fn, bytes) && fits_resident(fn, threads, bytes, grid);
+}
+
 // diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
 inline thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 inline void ev_begin(hipStream_t st) { if (g_ev_start) hipEventRecord(g_ev_start, st); }

@@ -17,6 +17,7 @@ Goldens:
   G7 realdata       first pairs of shipped yeast / breast CSVs with a seeded H=8 net
   G9 datahandler    readcsv + DataHandler split / batches / validation sets, numpy stream seeded (datahandler.py, csvreader.py)
   G10 analysis      gene-influence scoring loop (find_gene_influences.py:64-77) and calculate_trajectory (datahandler.py:310-340)
+  G12 spread        the reference's OWN dopri5 gradients at rtol * {0.85 ... 1.15} and an fp64 tight-tolerance truth (G4 inputs)
   G11 hill          rate expressions of the 350-gene ground-truth network: rates and LSODA trajectories (GraphGRN_core.R:425-486)
   G8 prior          read_prior_matrix (dense + triplet formats) and prior_grad = X @ P   (train_insilico.py:64-73,207-211)
 """
@@ -553,9 +554,44 @@ def g11_hill():
     save("g11_hill", names=np.array(names), eqns=np.array(exprs), X=X, rates=rates, times=times, x0=x0, traj=traj)
 
 
+# ---------------------------------------------------------------- G12 (spread of the reference's own gradients)
+def g12_spread():
+    """rtol = 1e-7 is below fp32 epsilon: accept/reject decisions of the adaptive solver are rounding noise, so the
+    reference's own fp32 gradient moves when rtol is jittered.  This captures how far: its gradients at
+    rtol * {0.85 ... 1.15} (seven values) and the fp64 tight-tolerance gradient of the same problem, for every G4 case that has
+    gradients.  tests assert that the engine (and the oracle) are no further from the truth than the reference is."""
+    g4 = np.load(os.path.join(OUT, "g4_dopri5.npz"))
+    out = {}
+    N, H = 32, 6
+    net = make_net(N, H, seed=21, dense_std=0.2, neg_g_frac=0.1)
+    net64 = make_net(N, H, seed=21, dense_std=0.2, neg_g_frac=0.1).double()
+
+    def grads_of_run(nn, y0, t, G, rtol, atol):
+        for p in nn.parameters():
+            p.grad = None
+        y = y0.clone().requires_grad_(True)
+        sol = odeint_adjoint(nn, y, t, rtol=rtol, atol=atol)
+        (sol * G).sum().backward()
+        d = {"grad_y0": y.grad.numpy().copy()}
+        d.update(grads_np(nn))
+        return d
+
+    for tname in ("t2", "t4", "t_dec"):
+        for yname in ("single", "batch"):
+            key = "%s/%s/" % (tname, yname)
+            y0 = torch.from_numpy(g4["y0_" + yname])
+            t = torch.from_numpy(g4[tname])
+            G = torch.from_numpy(g4[key + "G"])
+            truth = grads_of_run(net64, y0.double(), t.double(), G.double(), 1e-12, 1e-14)
+            out.update(pfx(truth, key + "truth64/"))
+            for j, f in enumerate((0.85, 0.9, 0.95, 1.0, 1.05, 1.1, 1.15)):
+                out.update(pfx(grads_of_run(net, y0, t, G, 1e-7 * f, 1e-9), key + "jit%d/" % j))
+    save("g12_spread", **out)
+
+
 if __name__ == "__main__":
     for only, fn in (("--only-g8", "g8_prior"), ("--only-g9", "g9_datahandler"), ("--only-g10", "g10_analysis"),
-                     ("--only-g11", "g11_hill")):
+                     ("--only-g11", "g11_hill"), ("--only-g12", "g12_spread")):
         if only in sys.argv:
             globals()[fn]()
             sys.exit(0)
@@ -569,3 +605,4 @@ if __name__ == "__main__":
     g9_datahandler()
     g10_analysis()
     g11_hill()
+    g12_spread()

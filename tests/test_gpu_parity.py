@@ -14,7 +14,7 @@ KEYS = ("Ws", "bs", "Wp", "bp", "Wa", "g")
 TOL_RHS = 5e-6        # fp32 sums in a different order (tree/shuffle vs MKL)
 TOL_FIXED = 1e-5      # north_star tolerance on trajectories
 TOL_DOPRI = 1e-5
-TOL_DOPRI_GRAD = 5e-5  # see tests/test_oracle_vs_golden.py: adaptive fp32 noise floor of the gradients
+TOL_DOPRI_GRAD = 3e-5  # see tests/test_oracle_vs_golden.py: adaptive fp32 noise floor of the gradients
 
 
 @pytest.fixture(scope="module")
@@ -138,6 +138,32 @@ def test_g4_dopri5(pa, dev, tname, yname):
         got = grads_of(net)
         for k in KEYS:
             assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+
+
+def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(pa, dev):
+    """The engine's dopri5 gradients against the fp64 tight-tolerance truth of the six G4 problems, held to the
+    reference's OWN measured distance from that truth (golden G12: its fp32 gradients at rtol * {0.85 ... 1.15};
+    rtol = 1e-7 is below fp32 epsilon, so this distance -- median 7.7e-6, max 1.3e-5 -- is the noise floor of the
+    algorithm, not of an implementation): median within 1.25 x the reference's median, worst case within 2 x its worst."""
+    g, sp = load_golden("g4_dopri5"), load_golden("g12_spread")
+    net = make_net(pa, dev, sub(g, "p_"))
+    ref_err, our_err = [], []
+    for tname in ("t2", "t4", "t_dec"):
+        for yname in ("single", "batch"):
+            c, s = sub(g, "%s/%s/" % (tname, yname)), sub(sp, "%s/%s/" % (tname, yname))
+            names = ["grad_y0"] + ["grad_" + k for k in KEYS]
+            ref_err += [max(relerr(s["jit%d/%s" % (j, n)], s["truth64/" + n]) for n in names) for j in range(7)]
+            zero_grads(net)
+            y0r = torch.from_numpy(g["y0_" + yname]).to(dev).requires_grad_(True)
+            s2 = pa.odeint_adjoint(net, y0r, torch.from_numpy(g[tname]).to(dev))
+            (s2 * torch.from_numpy(c["G"]).to(dev)).sum().backward()
+            got = grads_of(net)
+            our_err.append(max([relerr(y0r.grad.cpu().numpy(), s["truth64/grad_y0"])] +
+                               [relerr(got[k], s["truth64/grad_" + k]) for k in KEYS]))
+    print("gradient error vs fp64 truth: engine median %.2e max %.2e | reference median %.2e max %.2e" %
+          (np.median(our_err), max(our_err), np.median(ref_err), max(ref_err)))
+    assert np.median(our_err) <= 1.25 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
+    assert max(our_err) <= 2.0 * max(ref_err), (max(our_err), max(ref_err))
 
 
 def test_g4_per_sample_loop_as_one_launch(pa, dev):
@@ -354,15 +380,24 @@ def test_full_size_breast_properties(pa, dev, oracle):
     rows = [0, 100, 255]
     ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
-    adj_ref, _ = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
-                                                    method="dopri5", theta_in_norm=False)
+    adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
+                                                          method="dopri5", theta_in_norm=False)
     assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    full = grads_of(net)
+    # parameter gradients at full size against the oracle: the engine on exactly the sampled rows (the quadrature
+    # kernel at N = 11165; linearity over sub-batches below ties the 256-row gradient to such pieces)
+    zero_grads(net)
+    yr = y0t.detach()[rows].clone().requires_grad_(True)
+    sr = pa.odeint_adjoint(net, yr, tt[rows])
+    (sr * G[:, rows]).sum().backward()
+    g_rows = grads_of(net)
+    for k in KEYS:
+        assert relerr(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
     # batch invariance: a sub-batch gives the same rows
     sub_rows = list(range(16, 48))
     s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
     assert relerr(s2[1].cpu().numpy(), s[1, sub_rows].cpu().numpy()) < 2e-6
     # parameter gradients == sum over sub-batches (linearity in the batch)
-    full = grads_of(net)
     acc = {k: np.zeros_like(v) for k, v in full.items()}
     for lo in range(0, B, 64):
         zero_grads(net)
@@ -432,7 +467,7 @@ def test_full_size_bcell_properties(pa, dev, oracle):
     r = np.random.RandomState(9)
     y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
     y0[200] = y0[5]
-    t = np.tile(np.array([[0.0, 0.5]], np.float32), (B, 1))
+    t = np.tile(np.array([[0.0, 1.0]], np.float32), (B, 1))      # the interval bench.py --workload bcell integrates
     y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
     tt = torch.from_numpy(t).to(dev)
     sol = pa.odeint_adjoint(net, y0t, tt)
@@ -445,13 +480,20 @@ def test_full_size_bcell_properties(pa, dev, oracle):
     rows = [1, 254]
     ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
-    adj_ref, _ = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
-                                                    method="dopri5", theta_in_norm=False)
+    adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
+                                                          method="dopri5", theta_in_norm=False)
     assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    full = grads_of(net)
+    zero_grads(net)                                  # parameter gradients of exactly the sampled rows against the oracle
+    yr = y0t.detach()[rows].clone().requires_grad_(True)
+    sr = pa.odeint_adjoint(net, yr, tt[rows])
+    (sr * G[:, rows]).sum().backward()
+    g_rows = grads_of(net)
+    for k in KEYS:
+        assert relerr(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
     sub_rows = list(range(100, 132))
     s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
     assert relerr(s2[1].cpu().numpy(), s[1, sub_rows].cpu().numpy()) < 2e-6
-    full = grads_of(net)
     acc = {k: np.zeros_like(v) for k, v in full.items()}
     for lo in range(0, B, 128):
         zero_grads(net)
@@ -543,6 +585,46 @@ def test_deferred_status_mode(pa, dev):
         pa.check_pending_status(wait=True)
     finally:
         pa.set_status_mode("immediate")
+
+
+def test_solve_beside_a_busy_second_stream(pa, dev):
+    """The persistent kernels wait for each other's rows, so every workgroup of a launch must become resident.  The
+    library refuses a grid the device cannot hold (occupancy query -> PHX_ERR_LAUNCH); work on ANOTHER stream can only
+    delay residency until its own workgroups drain.  A solve launched beside a stream that keeps the chip busy with
+    GEMMs must finish with the same result, far inside the 5 s spin limit."""
+    import time
+    N, H, B = 2000, 40, 64
+    p = rand_params(N, H, seed=3, std=0.03)
+    net = make_net(pa, dev, p)
+    y0 = torch.rand(B, 1, N, device=dev)
+    t = torch.tensor([[0.0, 0.3]], device=dev).repeat(B, 1)
+
+    def run():
+        zero_grads(net)
+        yy = y0.clone().requires_grad_(True)
+        sol = pa.odeint_adjoint(net, yy, t)
+        sol.sum().backward()
+        return sol.detach().clone(), yy.grad.clone(), grads_of(net)
+
+    quiet = run()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev)
+    stop = time.perf_counter() + 0.6
+    results = []
+    with torch.cuda.stream(side):
+        for _ in range(40):                      # ~40 x 1.5 ms of 256-workgroup-plus GEMMs queued on the side stream
+            a = (a @ a).clamp_(-1, 1)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        results.append(run())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert elapsed < 3.0, elapsed
+    for sol, gy, gp in results:
+        assert torch.equal(sol, quiet[0]) and torch.equal(gy, quiet[1])
+        for k in KEYS:
+            assert np.array_equal(gp[k], quiet[2][k]), k
 
 
 # --------------------------------------------------------------------------- engine variants

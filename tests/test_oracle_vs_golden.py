@@ -12,10 +12,11 @@ TOL_FIXED = 5e-6
 # north_star tolerance on trajectories of converged adaptive solves: 1e-5 relative
 TOL_DOPRI = 1e-5
 # gradients of the adaptive adjoint: rtol=1e-7 is below fp32 epsilon, so accept/reject decisions are
-# rounding noise and two fp32 implementations land on different step sequences.  Measured here
-# (DESIGN.md "parity tolerances"): the reference's own fp32 gradient is 4e-6..1.8e-5 from the fp64
-# tight-tolerance truth when rtol is jittered by +-10%; the oracle spans 5e-6..2.6e-5.
-TOL_DOPRI_GRAD = 5e-5
+# rounding noise and two fp32 implementations land on different step sequences.  Measured (golden G12, captured
+# from the reference): its own fp32 gradient is 2.6e-6..1.3e-5 (median 7.7e-6) from the fp64 tight-tolerance truth
+# when rtol is jittered by +-15 %, so two such gradients differ by up to ~2.5e-5; test_g12_* below holds the oracle
+# to the reference's own distance from the truth, this constant bounds oracle-vs-reference differences.
+TOL_DOPRI_GRAD = 3e-5
 
 
 @pytest.mark.parametrize("case", ["sparse", "dense", "odd"])
@@ -82,6 +83,25 @@ def test_g4_dopri5(oracle, tname, yname):
                 assert relerr(grads[k], c["grad_" + k]) < TOL_DOPRI_GRAD, (k, theta_in_norm)
 
 
+def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(oracle):
+    """G12: the reference's own fp32 gradients at rtol * {0.85 ... 1.15} against an fp64 tight-tolerance truth of the
+    same six G4 problems: the noise floor of this solver at rtol = 1e-7 < fp32 epsilon, MEASURED (median 7.7e-6, max
+    1.3e-5 relative).  The oracle must sit in the same distribution: median no worse than 1.25 x the reference's median,
+    worst case within 2 x the reference's worst."""
+    g, sp = load_golden("g4_dopri5"), load_golden("g12_spread")
+    net = net_from(oracle, g)
+    ref_err, our_err = [], []
+    for tname in ("t2", "t4", "t_dec"):
+        for yname in ("single", "batch"):
+            c, s = sub(g, "%s/%s/" % (tname, yname)), sub(sp, "%s/%s/" % (tname, yname))
+            names = ["grad_y0"] + ["grad_" + k for k in KEYS]
+            ref_err += [max(relerr(s["jit%d/%s" % (j, n)], s["truth64/" + n]) for n in names) for j in range(7)]
+            adj, grads = oracle.adjoint_backward(net, g[tname], c["sol"], c["G"], method="dopri5", theta_in_norm=False)
+            our_err.append(max([relerr(adj, s["truth64/grad_y0"])] + [relerr(grads[k], s["truth64/grad_" + k]) for k in KEYS]))
+    assert np.median(our_err) <= 1.25 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
+    assert max(our_err) <= 2.0 * max(ref_err), (max(our_err), max(ref_err))
+
+
 def test_g4_per_sample_loop(oracle):
     g = load_golden("g4_dopri5")
     net = net_from(oracle, g)
@@ -143,3 +163,36 @@ def test_g7_realdata(oracle, name):
         assert relerr(adj, c["grad_y0"]) < TOL_DOPRI_GRAD
         for k in KEYS:
             assert relerr(grads[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+
+
+@pytest.mark.parametrize("name,N,H,t1,sparse", [("yeast-like C3", 2000, 120, 5.0, True), ("breast-like C4", 11165, 40, 0.0051, False)])
+def test_theta_block_of_the_adjoint_norm_is_inert_at_training_scale(oracle, name, N, H, t1, sparse):
+    """adjoint.py:72-78 puts a fourth block -- the accumulated parameter gradient -- into the mixed Linf/RMS norm of
+    the backward solve; the engine's controllers see [t, y, a] only (a per-trajectory P-sized state would be needed).
+    MEASUREMENT behind that choice, at full C3 / C4 size with the oracle, which implements both: with the cotangent of
+    the training loss (mean over B*N elements, train_insilico.py:132: |dL/dy| ~ 1/(B N)) the theta block never wins
+    the max -- step sequence AND results are bit-identical with and without it, because atol = 1e-9 dominates the
+    tolerance of every adjoint-sized quantity.  (With O(1) cotangents it does win: a few more steps, results within
+    5e-6 of each other -- see DESIGN.md; the B-cell shape shows 1e-7 even at training scale.)"""
+    r = np.random.RandomState(10)
+    std = 0.05 if sparse else 0.02
+    p = {"Ws": r.randn(H, N) * std, "bs": r.randn(H) * 0.1, "Wp": r.randn(H, N) * std, "bp": r.randn(H) * 0.1,
+         "Wa": r.randn(N, 2 * H) * std, "g": r.rand(1, N)}
+    if sparse:
+        for k in ("Ws", "Wp", "Wa"):
+            p[k] = p[k] * (r.rand(*p[k].shape) < 0.05)
+    p = {k: v.astype(np.float32) for k, v in p.items()}
+    net = oracle.Net(p["Ws"], p["bs"], p["Wp"], p["bp"], p["Wa"], p["g"])
+    B = 2
+    y0 = (np.clip(r.randn(B, N) * 0.4, -2.5, 4.0) if sparse else np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07)).astype(np.float32)
+    t = np.tile(np.array([[0.0, t1]], np.float32), (B, 1))
+    ref = oracle.odeint_per_sample(net, y0, t, method="dopri5")
+    G = np.zeros((B, 2, N), np.float32)
+    G[:, 1] = 2.0 * r.randn(B, N) * 0.1 / (256 * N)          # d mean((pred - target)^2) / d pred for a 256-sample batch
+    out = {}
+    for th in (True, False):
+        out[th] = oracle.adjoint_backward_per_sample(net, t, ref, G, method="dopri5", theta_in_norm=th, return_stats=True)
+    assert out[True][2] == out[False][2] and out[True][3] == out[False][3]           # nfe, nsteps
+    assert np.array_equal(out[True][0], out[False][0])
+    for k in KEYS:
+        assert np.array_equal(out[True][1][k], out[False][1][k]), k
