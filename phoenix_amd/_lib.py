@@ -42,7 +42,7 @@ STATUS_TEXT = {
 
 
 def lib_path():
-    return _build.LIB
+    return os.environ.get("PHX_LIB", _build.LIB)     # PHX_LIB: a diagnostic build of the same ABI
 
 
 def load():

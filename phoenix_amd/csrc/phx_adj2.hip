@@ -122,7 +122,7 @@ int prof_wave()
 }
 int stagger_ticks()
 {
-    if (const char *e = getenv("PHX_STAGGER_US")) return std::max(0, atoi(e)) * 100;
+    if (const char *e = getenv("PHX_STAGGER_US")) return atoi(e) < 0 ? -1 : atoi(e) * 100;   // < 0: generic sweeps only
     return 0;
 }
 
