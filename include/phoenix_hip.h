@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 1
+#define PHX_ABI_VERSION 2
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -73,6 +73,10 @@ typedef struct phx_solve_opts {
     int t_is_f32;       /* 1: the caller's t tensor was float32 (fixed-grid dt is then formed in fp32);
                            2: ... and the buffer passed as `t` still holds float32 values (no conversion) */
     long long max_num_steps; /* <=0: 2^31-1 like the reference (rk_common.py:110) */
+    int calls;          /* phx_odeint with PHX_CTRL_SHARED only; > 1: the B rows are `calls` independent odeint calls of
+                           B/calls rows each (rows of a call contiguous), every call under its own shared step
+                           controller -- the loop of find_gene_influences.py:64-77 in one launch.  0/1: one call.
+                           The adjoint entry point ignores it. */
 } phx_solve_opts;
 
 int phx_abi_version(void);
@@ -83,6 +87,8 @@ int phx_device_cus(void);
 /* Workspace size (bytes) for one call of entry point `op` with this shape. */
 enum phx_op { PHX_OP_RHS_FORWARD = 0, PHX_OP_RHS_VJP = 1, PHX_OP_ODEINT = 2, PHX_OP_ADJOINT = 3 };
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T);
+/* ... for phx_odeint with opts->calls = calls (0: this batch of calls cannot be planned, solve the calls one by one) */
+size_t phx_odeint_calls_workspace_bytes(int N, int H, int B, int T, int calls);
 
 /* Replaces ODENet.forward / prior_only_forward (odenet.py:85-98): out[B,N] = f(y[B,N]). */
 int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int prior_only,

@@ -2,7 +2,7 @@
 
 Drop-in for the reference's hot path only:  `from phoenix_amd import odeint_adjoint as odeint`
 replaces `from torchdiffeq import odeint_adjoint as odeint` (train_insilico.py:15-18)."""
-from .odeint import SOLVERS, odeint, odeint_adjoint, odeint_per_sample  # noqa: F401
+from .odeint import SOLVERS, odeint, odeint_adjoint, odeint_calls, odeint_per_sample  # noqa: F401
 from .odenet import ODENet  # noqa: F401
 from .engine import check_pending_status, set_status_mode  # noqa: F401
 from .training import training_step  # noqa: F401

@@ -20,12 +20,13 @@ class PhxGrads(C.Structure):
 
 class PhxSolveOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("control", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
-                ("t_per_sample", C.c_int), ("t_is_f32", C.c_int), ("max_num_steps", C.c_longlong)]
+                ("t_per_sample", C.c_int), ("t_is_f32", C.c_int), ("max_num_steps", C.c_longlong), ("calls", C.c_int)]
 
 
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
-           "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel")
+           "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
+           "phx_odeint_calls_workspace_bytes")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -73,6 +74,8 @@ def load():
     lib.phx_debug_set_kernel_events.argtypes = [vp, vp]
     lib.phx_debug_set_kernel_events.restype = None
     lib.phx_debug_adjoint_kernel.argtypes = [C.c_int] * 5
-    assert lib.phx_abi_version() == 1
+    lib.phx_odeint_calls_workspace_bytes.argtypes = [C.c_int] * 5
+    lib.phx_odeint_calls_workspace_bytes.restype = C.c_size_t
+    assert lib.phx_abi_version() == 2
     _LIB = lib
     return lib

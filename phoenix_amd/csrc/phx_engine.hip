@@ -795,8 +795,11 @@ constexpr int ADJ_NW_CAP = 4;   // the augmented kernel needs the 512-register b
 
 // picks (NW, TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency
 bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hidden frag tiles / HT */,
-             size_t lds_per_block_extra, D1 *out, size_t ctl_extra_per_traj = 0, int nw_cap = 8)
+             size_t lds_per_block_extra, D1 *out, size_t ctl_extra_per_traj = 0, int nw_cap = 8, int calls = 1)
 {
+    // calls > 1 (shared control only): B = calls x Bcall rows, one batch group per call
+    if (calls > 1 && (control != PHX_CTRL_SHARED || B % calls != 0)) return false;
+    const int Bcall = calls > 1 ? B / calls : 0;
     const int cus = num_cus();
     if (cus <= 0 || force_v0()) return false;
     // H > 128: the hidden layer is cut into HC chunks of Hc <= 128 rows whose weights take turns in LDS
@@ -804,19 +807,20 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     const int HT = Hc <= 48 ? 3 : 8;
     if (HC > 1) nvec += (nvec >= NVEC_ADJ) ? (NVEC_ADJ_CH - NVEC_ADJ) : (NVEC_FWD_CH - NVEC_FWD);
     const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4 + lds_per_block_extra;
-    const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
+    const int nblk = (N + 31) / 32, ntt = ((Bcall ? Bcall : B) + 15) / 16;
     long long best_cost = -1;
     D1 best{};
     int nwmax = std::min(nw_cap, (HT == 3 ? 8 : 4));
     if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
     for (int NW = nwmax; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 4; TPW <<= 1) {
-            const int slots = NW * TPW, TG = (ntt + slots - 1) / slots;
+            const int slots = NW * TPW, TG = Bcall ? calls : (ntt + slots - 1) / slots;
+            if (Bcall && slots < ntt) continue;   // a call is one group
             // a single group smaller than its wave slots: the spare waves become helpers of the exchange (the
             // reduce-scatter splits a row's members over all NW waves), the tile count is what the batch needs
-            const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
+            const int ntg = (TG == 1 || Bcall) ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
             const bool helpers = ntg < slots;
-            if (control == PHX_CTRL_SHARED && TG != 1) continue;
+            if (control == PHX_CTRL_SHARED && TG != 1 && !Bcall) continue;
             const size_t cb = ctl_bytes(Bt) + ctl_extra_per_traj * Bt;
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
@@ -833,6 +837,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
                     best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
                     best.TPW = TPW; best.G = G; best.TG = TG; best.nblk = nblk; best.ntg = ntg; best.Bt = Bt;
                     best.nvec = nvec; best.BN = (long long)B * N; best.HC = HC; best.Hc = Hc;
+                    best.Bcall = Bcall; best.cntN = (long long)(Bcall ? Bcall : B) * N;
                 }
                 break;  // smallest feasible NB for this (NW, TPW) is the cheapest
             }
@@ -857,6 +862,18 @@ int pick_chunk_v1(int N, int H, int B, int T, int control, bool adj)
     if (control != PHX_CTRL_PER_TRAJECTORY) return 0;
     for (int bc = 4096; bc >= 16; bc >>= 1)
         if (bc < B && ok(bc)) return bc;
+    return 0;
+}
+
+// `calls` independent shared-control odeint calls of B/calls rows each: the largest number of calls one launch takes
+// (one batch group per call), 0 when not even a single call can be planned.
+int pick_calls_v1(int N, int H, int B, int T, int calls)
+{
+    if (calls < 1 || B % calls != 0) return 0;
+    const int Bcall = B / calls;
+    D1 d1;
+    for (int n = std::min(calls, std::max(1, num_cus())); n >= 1; --n)
+        if (plan_v1(N, H, n * Bcall, T, PHX_CTRL_SHARED, NVEC_FWD, 2, 0, &d1, 0, 8, n)) return n;
     return 0;
 }
 
@@ -1222,6 +1239,16 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     return need;
 }
 
+size_t phx_odeint_calls_workspace_bytes(int N, int H, int B, int T, int calls)
+{
+    if (N <= 0 || H <= 0 || B <= 0 || T < 0 || calls < 1 || B % calls != 0) return 0;
+    if (calls == 1) return phx_workspace_bytes(PHX_OP_ODEINT, N, H, B, T);
+    const int n = pick_calls_v1(N, H, B, T, calls);
+    D1 d1;
+    if (n < 1 || !plan_v1(N, H, n * (B / calls), T, PHX_CTRL_SHARED, NVEC_FWD, 2, 0, &d1, 0, 8, n)) return 0;
+    return make_layout1(d1, 2 * d1.HT, false).total;
+}
+
 int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int prior_only, void *workspace,
                     size_t workspace_bytes, void *stream)
 {
@@ -1357,12 +1384,21 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    // several calls in one batch (analysis callers): every call keeps its own shared controller, a launch takes as many
+    // calls as there are batch groups to run them (MFMA kernels only)
+    const int calls = o->calls > 1 ? o->calls : 1;
+    int Bcall = 0;
+    if (calls > 1) {
+        if (o->control != PHX_CTRL_SHARED || B % calls != 0) return PHX_ERR_BAD_ARG;
+        Bcall = B / calls;
+    }
     // v1: MFMA kernels with LDS-resident weights, when the shape fits (large batches: in chunks)
-    const int chunk_f = pick_chunk_v1(p->N, p->H, B, T, o->control, false);
+    const int chunk_f = Bcall ? pick_calls_v1(p->N, p->H, B, T, calls) * Bcall : pick_chunk_v1(p->N, p->H, B, T, o->control, false);
+    if (Bcall && chunk_f == 0) return PHX_ERR_BAD_ARG;
     for (int b0 = 0; chunk_f > 0 && b0 < B; b0 += chunk_f) {
         D1 d1;
         const int bc = std::min(chunk_f, B - b0);
-        if (!plan_v1(p->N, p->H, bc, T, o->control, NVEC_FWD, 2, 0, &d1)) return PHX_ERR_BAD_ARG;
+        if (!plan_v1(p->N, p->H, bc, T, o->control, NVEC_FWD, 2, 0, &d1, 0, 8, Bcall ? bc / Bcall : 1)) return PHX_ERR_BAD_ARG;
         d1.BN = (long long)B * p->N;   // time stride of the caller's [T,B,N] arrays
         {
             const float *y0 = y0_all + (long long)b0 * p->N;

@@ -29,12 +29,19 @@ _ws_bytes = {}
 _PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS")
 
 
-def _workspace(op, N, H, B, T, device):
+def _workspace(op, N, H, B, T, device, calls=1):
     # the size query re-plans the launch on the host: remembered per shape (and per diagnostic switch setting)
-    key = (op, N, H, B, T) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    key = (op, N, H, B, T, calls) + tuple(os.environ.get(k) for k in _PLAN_ENV)
     nbytes = _ws_bytes.get(key)
     if nbytes is None:
-        nbytes = _ws_bytes[key] = _lib.load().phx_workspace_bytes(op, N, H, B, T)
+        if calls > 1:
+            nbytes = _lib.load().phx_odeint_calls_workspace_bytes(N, H, B, T, calls)
+            if nbytes == 0:
+                raise ValueError("a batch of %d calls x %d trajectories cannot be planned for N=%d, H=%d" %
+                                 (calls, B // calls, N, H))
+        else:
+            nbytes = _lib.load().phx_workspace_bytes(op, N, H, B, T)
+        _ws_bytes[key] = nbytes
     key = (device.index, torch.cuda.current_stream().cuda_stream, op)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -224,22 +231,26 @@ def prior_mse(p, X, target):
     return loss, cot
 
 
-def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps):
+def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls=1):
     return _lib.PhxSolveOpts(_lib.METHODS[method], control, float(rtol), float(atol), int(t_per_sample),
-                             int(t_is_f32), int(max_num_steps))
+                             int(t_is_f32), int(max_num_steps), int(calls))
 
 
-def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0, stats=None):
+def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps=0, stats=None,
+                  calls=1):
     """y0 [B,N] f32, t64 [T] or [B,T] f64 (device) -> sol [T,B,N], status[B], nfe[B], nsteps[B].
     The engine writes NaN into the outputs a failed trajectory never reached (a backward solve launched before the
-    status is read then stops at once)."""
+    status is read then stops at once).  calls > 1 (shared control): the rows are `calls` independent odeint calls
+    of B/calls rows each, every call with its own step controller (include/phoenix_hip.h, phx_solve_opts.calls)."""
     B, N = y0.shape
+    if calls > 1 and (control != _lib.CTRL_SHARED or B % calls):
+        raise ValueError("calls > 1 needs shared step control and B divisible by calls")
     T = t64.shape[-1]
     sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
     if stats is None:
         stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
-    ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device)
-    o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)
+    ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device, calls)
+    o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls)
     _check_call(_lib.load().phx_odeint(C.byref(p.c), _p(y0), _p(t64), B, T, C.byref(o), _p(sol), _p(stats[0]),
                                        _p(stats[1]), _p(stats[2]), _p(ws), nb, _stream_ptr()))
     return sol, stats[0], stats[1], stats[2]

@@ -166,6 +166,31 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_
     return (out, nfe, nsteps) if return_stats else out
 
 
+def odeint_calls(func, y0s, t, rtol=1e-7, atol=1e-9, method=None, options=None):
+    """K forward-only `odeint(func, y0s[k], t, ...)` calls in as few launches as the device has room for:
+        y0s [K, *shape] (shape = [B,1,N] or [B,N]), t [T]  ->  [K, T, *shape]  (a view of the engine's [T, K*B, N]).
+    Every call keeps the reference's batch semantics -- ONE adaptive step size shared by its B trajectories, chosen
+    from its own error norm -- so the result equals the K separate calls (the analysis loop of
+    find_gene_influences.py:64-77 issues 2 per gene).  Falls back to K launches where the batched plan does not
+    exist (shapes served by the VALU engine)."""
+    K = y0s.shape[0]
+    if K == 1:
+        return odeint(func, y0s[0], t, rtol, atol, method, options).unsqueeze(0)
+    y0, t, rtol, atol, method, options = _check_inputs(func, y0s, t, rtol, atol, method, options)
+    params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
+    if per_sample or control != _lib.CTRL_SHARED:
+        raise ValueError("odeint_calls: one shared time grid, batch_control='shared'")
+    engine.check_pending_status()
+    p = engine.params_cached(*params)
+    try:
+        sol, status, _, _ = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol, atol, per_sample,
+                                                 t_is_f32, int(options.get("max_num_steps", 0)), calls=K)
+    except ValueError:
+        return torch.stack([odeint(func, y0s[k], t, rtol, atol, method, options) for k in range(K)])
+    engine.raise_for_status(status)
+    return sol.reshape((sol.shape[0], K) + tuple(y0s.shape[1:])).transpose(0, 1)
+
+
 def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None,
                    adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
     """adjoint.py:165-204.  Gradients flow to y0 and to the six ODENet parameters."""

@@ -12,10 +12,11 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_grads(module, scale=None):
+def allreduce_grads(module, scale=None, extra=()):
     """sum-all-reduce every parameter gradient in ONE grouped collective (RCCL group call: no flat copy of the
     P = 4HN+2H+N floats and no copy back -- the gradients are reduced where autograd left them); `scale` (e.g. 1/world
-    for a mean loss over the global batch) is applied after the reduction."""
+    for a mean loss over the global batch) is applied after the reduction.  `extra`: further tensors summed in the same
+    group call (not scaled)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
     ps = [p for p in module.parameters() if p.requires_grad]
@@ -27,16 +28,63 @@ def allreduce_grads(module, scale=None):
         for p in ps:
             p.grad = p.grad.contiguous()
         grads = [p.grad for p in ps]
+    group = grads + list(extra)
     try:
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+            dist.all_reduce_coalesced(group, op=dist.ReduceOp.SUM)
     except (AttributeError, RuntimeError):   # backend without the grouped form: one collective per tensor
-        for g in grads:
+        for g in group:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
     if scale is not None:
         torch._foreach_mul_(grads, scale)
+
+
+class GradSync:
+    """`grad_sync` of `training_step` for data-parallel runs: the gradient all-reduce, plus agreement on failure.
+
+    A solve that fails on ONE rank (max_num_steps, dt underflow, a lost co-residency check) raises there and would
+    leave the other ranks waiting in the collective.  training_step hands the exception to this object instead; a
+    failure flag rides in the same group call as the gradients, the failing rank re-raises after the collective and
+    every other rank raises `RuntimeError` at a point that is the same on all of them: at once when the engine reads
+    statuses immediately (or on CPU), else at its next call / `finish()` -- the flag then comes back through pinned
+    memory like the deferred solver status (phoenix_amd.engine.set_status_mode) and costs no host synchronisation."""
+    collective_errors = True
+
+    def __init__(self, scale=None):
+        self.scale = scale
+        self._pending = None     # (pinned host flag, event) of the previous call
+
+    def check(self):
+        if self._pending is not None:
+            host, ev = self._pending
+            self._pending = None
+            ev.synchronize()
+            if float(host[0]) > 0:
+                raise RuntimeError("phoenix_amd: a solve failed on another rank in the previous step")
+
+    finish = check
+
+    def __call__(self, module, error=None):
+        from . import engine
+        self.check()
+        dev = next(module.parameters()).device
+        flag = torch.full((1,), 0.0 if error is None else 1.0, device=dev)
+        allreduce_grads(module, self.scale, extra=[flag])
+        if error is not None:
+            raise error
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dev.type != "cuda" or engine.status_mode() == "immediate":
+            if float(flag[0]) > 0:
+                raise RuntimeError("phoenix_amd: a solve failed on another rank")
+            return
+        host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (host, ev)
 
 
 def allreduce_scalars(*vals):

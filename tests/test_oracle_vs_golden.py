@@ -86,7 +86,7 @@ def test_g4_dopri5(oracle, tname, yname):
 def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(oracle):
     """G12: the reference's own fp32 gradients at rtol * {0.85 ... 1.15} against an fp64 tight-tolerance truth of the
     same six G4 problems: the noise floor of this solver at rtol = 1e-7 < fp32 epsilon, MEASURED (median 7.7e-6, max
-    1.3e-5 relative).  The oracle must sit in the same distribution: median no worse than 1.25 x the reference's median,
+    1.3e-5 relative).  The oracle must sit in the same distribution: median no worse than 1.5 x the reference's median (six cases against forty-two reference runs),
     worst case within 2 x the reference's worst."""
     g, sp = load_golden("g4_dopri5"), load_golden("g12_spread")
     net = net_from(oracle, g)
@@ -98,7 +98,7 @@ def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(oracle):
             ref_err += [max(relerr(s["jit%d/%s" % (j, n)], s["truth64/" + n]) for n in names) for j in range(7)]
             adj, grads = oracle.adjoint_backward(net, g[tname], c["sol"], c["G"], method="dopri5", theta_in_norm=False)
             our_err.append(max([relerr(adj, s["truth64/grad_y0"])] + [relerr(grads[k], s["truth64/grad_" + k]) for k in KEYS]))
-    assert np.median(our_err) <= 1.25 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
+    assert np.median(our_err) <= 1.5 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
     assert max(our_err) <= 2.0 * max(ref_err), (max(our_err), max(ref_err))
 
 

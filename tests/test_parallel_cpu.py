@@ -150,6 +150,57 @@ def test_two_rank_training_step_matches_single_process():
         assert abs(tot[0] - float(losses[0])) < 1e-5 and abs(tot[1] - float(losses[1])) < 1e-5
 
 
+def _failing_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phoenix_amd import parallel, training
+    B, n, K, batch, t, target, X, prior = _problem()
+    calls = [0]
+
+    def flaky(func, y0, t, method=None):     # rank 1's solve fails in its second step
+        calls[0] += 1
+        assert not (rank == 1 and calls[0] == 2), "max_num_steps exceeded"
+        return _stub_odeint_adjoint(func, y0, t, method)
+
+    training.odeint_adjoint = flaky
+    torch.manual_seed(1)
+    net = _StubNet(n)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    lo, hi = parallel.shard_range(B, rank, world)
+    h = _Handler(batch[lo:hi], t[lo:hi], target[lo:hi])
+    sync = parallel.GradSync(scale=1.0 / world)
+    outcome = []
+    for step in range(3):
+        try:
+            training.training_step(net, h, opt, "dopri5", hi - lo, False, False, X, prior, 0.7, grad_sync=sync)
+            outcome.append("ok")
+        except (AssertionError, RuntimeError) as e:
+            outcome.append(type(e).__name__ + ": " + str(e))
+            break
+    q.put((rank, outcome))
+    dist.destroy_process_group()
+
+
+def test_a_failed_solve_on_one_rank_stops_every_rank_in_the_same_step():
+    """training_step + parallel.GradSync: rank 1's solve fails in step 2 -> rank 1 raises the solver's AssertionError,
+    rank 0 raises RuntimeError in the SAME step instead of waiting forever in the gradient all-reduce."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] == ["ok", "AssertionError: max_num_steps exceeded"]
+    assert res[0][0] == "ok" and len(res[0]) == 2 and res[0][1].startswith("RuntimeError") and "another rank" in res[0][1]
+
+
 def test_shard_range_covers_everything():
     from phoenix_amd.parallel import shard_range
     for n in (1, 7, 256, 1023):
