@@ -21,6 +21,18 @@ with torch.no_grad():
     for prm in net.parameters():
         prm.mul_(0.5)
 genes = list(range(0, N, max(1, N // G)))[:G]
+# the loop as round 1 ran it: one odeint call per launch
+t = torch.from_numpy(np.arange(0, 1, 0.1)).to(dev)
+y = torch.rand(60, 1, N, device=dev) - 0.5
+with torch.no_grad():
+    pa.odeint(net, y, t, method="dopri5")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2 * len(genes)):
+        pa.odeint(net, y, t, method="dopri5")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print("N=%d H=%d  one odeint([60,1,N]) call per launch: %.1f solves/s" % (N, H, 2 * len(genes) / dt))
 for gpl in (1, 2, 4, 8):
     torch.manual_seed(1)
     gene_influence_scores(net, N, "dopri5", device=dev, genes=genes[:gpl], genes_per_launch=gpl)   # warm-up

@@ -5,7 +5,7 @@ R=$(pwd); OUT=$R/gpurun_out/${1:-cmp}; mkdir -p $OUT
 for wl in ${2:-breast insilico yeast}; do
   for var in ${3:-auto v1}; do
     unset PHX_ADJ PHX_ADJ2_NP
-    case $var in v1) export PHX_ADJ=v1;; np2) export PHX_ADJ2_NP=2;; np4) export PHX_ADJ2_NP=4;; esac
+    case $var in v1) export PHX_ADJ=v1;; np2) export PHX_ADJ=v2 PHX_ADJ2_NP=2;; np4) export PHX_ADJ=v2 PHX_ADJ2_NP=4;; esac
     timeout 600 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_${wl}_$var.json 2> $OUT/bench_${wl}_$var.err
     python - <<PY
 import json
