@@ -373,7 +373,7 @@ def main():
             cb["batched"] = batched
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(out))
+        os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
     if use_dist:
         import torch.distributed as dist
         dist.barrier()
@@ -381,4 +381,9 @@ def main():
 
 
 if __name__ == "__main__":
+    # the contract is ONE JSON line on stdout: native libraries (RCCL prints a version banner at the first collective)
+    # and anything else that writes to fd 1 go to stderr; the result line is written to the real stdout at the end
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()
