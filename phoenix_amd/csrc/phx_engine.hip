@@ -997,6 +997,7 @@ struct PlanBatch {
     long long Kp;
     size_t part, hdt, dtheta, total;   // workspace offsets
     size_t zl, losspart, total_fwd;    // forward path: per-chunk z rows, per-wave loss partials (fused MSE head)
+    size_t zl4, dgpart, total_vjp;     // full VJP: the four hidden sections in L_H layout per chunk, per-wave dg partials
 };
 
 bool plan_batch(int N, int H, int B, PlanBatch *out)
@@ -1032,6 +1033,9 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     out->hdt = take((size_t)4 * 16 * HT * out->Kp * 4);
     out->dtheta = take(PP * 4 * out->KS);
     out->total = off;
+    out->zl4 = take((size_t)out->chunk_tiles * 4 * HT * 4 * 64 * 4);
+    out->dgpart = take((size_t)d.TG * 4 * N * 4);
+    out->total_vjp = off;
     off = align_up(per_tile * out->chunk_tiles, 256);   // forward path reuses the partial buffer (half as many rows)
     out->zl = take((size_t)out->chunk_tiles * 2 * HT * 4 * 64 * 4);
     out->losspart = take((size_t)d.TG * d.G * 8 * sizeof(double));
@@ -1070,6 +1074,47 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
                        grads->WaT, grads->g, grads->bs, grads->bp);
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+// Full VJP of the RHS (or of prior_only_forward) on a batch, H <= 128: A -> R per row chunk, E (input VJP, f, dg
+// partials) per row chunk, C (parameter gradients) once.  Any of vjp_y / grads / f_out may be null.
+template <int HT>
+int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, float *vjp_y,
+                     const phx_grads *grads, float *f_out, int prior_only, char *base, hipStream_t st)
+{
+    float *part = (float *)(base + pb.part), *hdt = (float *)(base + pb.hdt), *dth = (float *)(base + pb.dtheta);
+    float *zl4 = (float *)(base + pb.zl4), *dgp = (float *)(base + pb.dgpart);
+    const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
+    const int full = prior_only ? 0 : 1;
+    const bool want_e = vjp_y || f_out || (grads && full);
+    if (grads && hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
+    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA) || !set_lds(k2_expand_vjp<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    const int hc = p->H;
+    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
+        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+        hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA, st,
+                           to_net(p), pb.d, y, cot, part, t0, nt, 0, hc, full);
+        const int tasks = nt * HT * 4;
+        hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
+                           pb.d.G, t0, nt, pb.Kp, 0, hc, want_e ? zl4 : (float *)nullptr);
+        if (want_e)
+            hipLaunchKernelGGL((k2_expand_vjp<HT>), dim3(pb.d.TG * pb.d.G), dim3(256), pb.ldsA, st, to_net(p), pb.d, y, cot,
+                               zl4, vjp_y, f_out, (grads && full) ? dgp : (float *)nullptr, prior_only, t0, nt,
+                               t0 == 0 ? 1 : 0);
+    }
+    if (grads) {
+        hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
+                           pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, 0, hc, full);
+        if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+        const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
+                           grads->WaT, grads->g, grads->bs, grads->bp);
+        if (full)
+            hipLaunchKernelGGL(k2_dg_finish, dim3((p->N + 255) / 256), dim3(256), 0, st, dgp, pb.d.TG * 4, p->N, p->g,
+                               grads->g);
+    }
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
@@ -1222,7 +1267,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     }
     if (op == PHX_OP_RHS_VJP) {
         PlanBatch pb;
-        if (plan_batch(N, H, B, &pb)) need = std::max(need, pb.total);
+        if (plan_batch(N, H, B, &pb)) need = std::max(need, std::max(pb.total, pb.total_vjp));
         PlanEval pe;
         for (int nbc = (H <= 48 ? 2 : EVAL_NBC_HT8); nbc <= (H <= 48 ? EVAL_NBC_HT3_MAX : EVAL_NBC_HT8); ++nbc)
             if (plan_eval(N, H, B, nbc, &pe)) need = std::max(need, make_layout_eval(pe, true).total);
@@ -1351,6 +1396,14 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, pe.d.TG * pe.d.NW, PP, p->N, p->H,
                                grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
             return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+        }
+    }
+    {   // everything else (dL/dy wanted, f wanted, or the full RHS): MFMA kernel chain A -> R -> E (+ C), H <= 128
+        PlanBatch pb;
+        if (p->H <= 128 && plan_batch(p->N, p->H, B, &pb) && pb.d.HC == 1 && pb.d.NB <= 6) {
+            if (workspace_bytes < pb.total_vjp) return PHX_ERR_WORKSPACE;
+            return pb.d.HT == 3 ? launch_batch_vjp<3>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st)
+                                : launch_batch_vjp<8>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st);
         }
     }
     const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);

@@ -266,6 +266,42 @@ def test_rhs_vjp_vs_oracle(pa, dev, oracle, N, H, B):
     assert relerr(out.detach().cpu().numpy(), oracle.rhs(onet, y, prior_only=True)) < TOL_RHS
 
 
+@pytest.mark.parametrize("prior_only", [False, True])
+@pytest.mark.parametrize("N,H,B", [(11165, 40, 300), (700, 100, 37), (513, 7, 3), (2000, 128, 130)])
+def test_rhs_vjp_kernel_chain_vs_oracle_rows_and_valu_engine(pa, dev, oracle, monkeypatch, N, H, B, prior_only):
+    """phx_rhs_vjp with dL/dy (the adjoint.py:116-119 shape on a whole batch) runs as the MFMA kernel chain; checked
+    against the oracle on sampled rows (input VJP), against the VALU engine for everything (input VJP, all six
+    parameter gradients), for every combination of requested outputs."""
+    from phoenix_amd import engine
+    p = rand_params(N, H, seed=3 * N + H, std=0.5 / np.sqrt(N))
+    net = make_net(pa, dev, p)
+    P = engine.params_cached(*pa.odenet.params_of(net))
+    r = np.random.RandomState(2)
+    y = torch.from_numpy((r.rand(B, N) * 3 - 1).astype(np.float32)).to(dev)
+    cot = torch.from_numpy(r.randn(B, N).astype(np.float32)).to(dev)
+    vjp, grads = engine.rhs_vjp(P, y, cot, prior_only=prior_only)
+    monkeypatch.setenv("PHX_ENGINE", "v0")
+    vjp0, grads0 = engine.rhs_vjp(P, y, cot, prior_only=prior_only)
+    monkeypatch.delenv("PHX_ENGINE")
+    assert relerr(vjp.cpu().numpy(), vjp0.cpu().numpy()) < TOL_RHS
+    for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+        a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
+        assert relerr(a, b) < 2 * TOL_RHS or (np.abs(b).max() == 0 and np.abs(a).max() == 0), k
+    # single outputs equal the combined call
+    v_only, none = engine.rhs_vjp(P, y, cot, prior_only=prior_only, want_grads=False)
+    assert none is None and torch.equal(v_only, vjp)
+    _, g_only = engine.rhs_vjp(P, y, cot, prior_only=prior_only, want_vjp_y=False)
+    assert relerr(g_only.Ws.cpu().numpy(), grads.Ws.cpu().numpy()) < 1e-6
+    assert relerr(g_only.g.cpu().numpy(), grads.g.cpu().numpy()) < 1e-6 or prior_only
+    # oracle on sampled rows (the input VJP of a row does not depend on the other rows)
+    if not prior_only:
+        rows = [0, B // 2, B - 1]
+        onet = onet_of(oracle, p)
+        vref, _, _ = oracle.rhs_vjp(onet, y[rows].cpu().numpy().reshape(len(rows), 1, N),
+                                    cot[rows].cpu().numpy().reshape(len(rows), 1, N))
+        assert relerr(vjp[rows].cpu().numpy(), vref.reshape(len(rows), N)) < TOL_RHS
+
+
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
 @pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1100, 16, 5)])
 def test_per_sample_solve_and_adjoint_vs_oracle(pa, dev, oracle, method, N, H, B):
