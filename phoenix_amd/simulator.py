@@ -83,6 +83,87 @@ class _Compiler(ast.NodeVisitor):
         raise ValueError("unsupported syntax in a rate expression: %s" % type(node).__name__)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# External inputs of a simulated data set (SimulationGRN_core_init_var.R:40-160).  Host-side sampling, as in the reference
+# (R); the draws come from numpy's generator, so a data set is statistically, not bitwise, the reference's.
+# ---------------------------------------------------------------------------------------------------------------------
+def create_input_models(input_names, prop_bimodal=0.0, rng=None):
+    """`createInputModels` (R:40-68): every input gene gets a one- or two-component normal mixture.
+    Bimodal (probability `prop_bimodal`): weights (p, 1-p), p ~ U(0.2, 0.8); means Beta(10,100) and Beta(10,10).
+    Unimodal: mean Beta(10,10).  sd = max(Beta(15,15) * min(mean, 1-mean)/3, 0.01) per component."""
+    rng = np.random.default_rng() if rng is None else rng
+    models = {}
+    for name in input_names:
+        if rng.random() < prop_bimodal:
+            p = rng.uniform(0.2, 0.8)
+            prop = np.array([p, 1.0 - p])
+            mean = np.array([rng.beta(10, 100), rng.beta(10, 10)])
+        else:
+            prop = np.array([1.0])
+            mean = np.array([rng.beta(10, 10)])
+        maxsd = np.minimum(mean, 1.0 - mean) / 3.0
+        sd = np.array([max(rng.beta(15, 15) * x, 0.01) for x in maxsd])
+        models[name] = {"prop": prop, "mean": mean, "sd": sd}
+    return models
+
+
+def vine_correlation(d, betaparam=5.0, rng=None):
+    """`vineS` (R:76-98): random correlation matrix by the C-vine construction of Lewandowski, Kurowicka and Joe (2009):
+    partial correlations 2 Beta(b, b) - 1 (smaller `betaparam` = stronger correlations) converted to correlations, then a
+    random simultaneous permutation of rows and columns.  The R loop starts at k = 2, so the first variable stays
+    uncorrelated with the others before the permutation; kept.  d < 3: identity (the R loop bounds are not meaningful)."""
+    rng = np.random.default_rng() if rng is None else rng
+    S = np.eye(d)
+    if d < 3:
+        return S
+    P = np.zeros((d, d))
+    for k in range(1, d - 1):             # R: k in 2:(d-1), 1-based
+        for i in range(k + 1, d):         # R: i in (k+1):d
+            P[k, i] = (rng.beta(betaparam, betaparam) - 0.5) * 2.0
+            p = P[k, i]
+            for l in range(k - 1, -1, -1):    # R: l in (k-1):1
+                p = p * np.sqrt((1.0 - P[l, i] ** 2) * (1.0 - P[l, k] ** 2)) + P[l, i] * P[l, k]
+            S[k, i] = S[i, k] = p
+    perm = rng.permutation(d)
+    return S[np.ix_(perm, perm)]
+
+
+def generate_input_data(models, numsamples, cor_strength=5.0, input_gene_var=1.0, rng=None):
+    """`generateInputData` (R:101-160): [numsamples, n_inputs] external inputs in [0, 1] and the mixture classes.
+    Every input is drawn from its mixture (component sd scaled by `input_gene_var`), out-of-range values are redrawn
+    until none is left; with `cor_strength > 0` the unimodal inputs are then made rank-correlated: a multivariate normal
+    sample with a `vine_correlation` matrix supplies the ranks, the sorted marginal draws supply the values (marginals
+    unchanged); bimodal inputs keep their own draws ("avoid correlated bimodal inputs")."""
+    rng = np.random.default_rng() if rng is None else rng
+    names = list(models)
+    X = np.full((numsamples, len(names)), -1.0)
+    classf = {}
+    for c, name in enumerate(names):
+        m = models[name]
+        mix = rng.choice(len(m["prop"]), size=numsamples, p=m["prop"])
+        while True:
+            out = (X[:, c] < 0) | (X[:, c] > 1)
+            if not out.any():
+                break
+            for comp in range(len(m["prop"])):
+                sel = out & (mix == comp)
+                X[sel, c] = rng.normal(m["mean"][comp], m["sd"][comp] * input_gene_var, size=int(sel.sum()))
+        if len(m["prop"]) > 1:
+            classf[name] = mix + 1            # R's components are numbered from 1
+    if cor_strength > 0 and numsamples > 1 and len(names) > 0:
+        dm = np.sort(X, axis=0)
+        cov = vine_correlation(len(names), cor_strength, rng)
+        cordata = rng.multivariate_normal(np.zeros(len(names)), cov, size=numsamples, method="eigh")
+        for c, name in enumerate(names):
+            if name in classf:
+                cordata[:, c] = X[:, c]
+            else:
+                ranks = np.argsort(np.argsort(cordata[:, c], kind="stable"), kind="stable")
+                cordata[:, c] = dm[ranks, c]
+        X = cordata
+    return X, classf
+
+
 def read_ode_system(path):
     """`ode_system_functions_*.csv`: columns node, eqn -> (names, expressions) in file order."""
     with open(path, newline="") as fh:
@@ -152,26 +233,42 @@ class HillSystem:
                                                          engine._stream_ptr()))
         return out
 
-    def sample_initial(self, numsamples, output_gene_var=1.0, rng=None):
-        """SimulationGRN_core_init_var.R:206-213: every gene ~ Beta(2/var, 2/var) shifted by its own U(-.25, .25),
-        clipped to [0, 1] (the reference draws external inputs from its input models; here they start like any
-        other gene and stay constant)."""
+    def sample_initial(self, numsamples, output_gene_var=1.0, rng=None, input_models=None, cor_strength=5.0,
+                       input_gene_var=1.0, prop_bimodal=0.0):
+        """Initial states of `simDataset` (SimulationGRN_core_init_var.R:165-213).  Regulated genes: Beta(2/var, 2/var)
+        shifted by the gene's own U(-.25, .25), clipped to [0, 1] (R:206-213).  Input genes ("input gene" rows of the
+        expression file, rate 0): drawn from their input models with rank-correlated unimodal inputs (R:177-184,
+        `generate_input_data`); `input_models=None` creates the models first (`create_input_models`, R:32-34)."""
         rng = np.random.default_rng() if rng is None else rng
         a = 2.0 / output_gene_var
         x = rng.beta(a, a, size=(numsamples, self.N)) + rng.uniform(-0.25, 0.25, size=(1, self.N))
-        return np.clip(x, 0.0, 1.0).astype(np.float32)
+        x = np.clip(x, 0.0, 1.0)
+        if self.is_input.any():
+            in_names = [n for n, f in zip(self.names, self.is_input) if f]
+            if input_models is None:
+                input_models = create_input_models(in_names, prop_bimodal, rng)
+            xin, self.last_input_classes = generate_input_data({n: input_models[n] for n in in_names}, numsamples,
+                                                                cor_strength, input_gene_var, rng)
+            x[:, self.is_input] = xin
+        return x.astype(np.float32)
 
 
 def generate_dataset(system, numsamples, time_stamps=(0.0, 2.0, 3.0, 7.0, 9.0), expnoise=0.0, dt_max=0.01, rng=None,
-                     path=None):
+                     path=None, derivative=False, **initial_kw):
     """One in-silico data set like the reference's `example_creator...R` run: `numsamples` trajectories at
     `time_stamps` (example_creator_for_chalmers_codebase_0noise.R:134-139), optional Gaussian measurement noise
     (`addNormNoise`, SimulationGRN_core_init_var.R:1-3, 260-265); written with `writecsv` if `path` is given.
+    `derivative=True` is the reference's `get_derivative_instead` branch (R:222-240): the table holds the rates at the
+    solution's states instead of the states, and zeros in the input columns.  `initial_kw` goes to
+    `HillSystem.sample_initial` (input models, `cor_strength`, `input_gene_var`, `output_gene_var`, `prop_bimodal`).
     Returns (data_np, t_np) in `readcsv`'s shapes."""
     from .data import writecsv
     rng = np.random.default_rng() if rng is None else rng
-    x0 = torch.from_numpy(system.sample_initial(numsamples, rng=rng)).to(system.device)
-    sol = system.simulate(x0, time_stamps, dt_max).cpu().numpy()            # [T, S, N]
+    x0 = torch.from_numpy(system.sample_initial(numsamples, rng=rng, **initial_kw)).to(system.device)
+    sol = system.simulate(x0, time_stamps, dt_max)                          # [T, S, N]
+    if derivative:
+        sol = system.rhs(sol.reshape(-1, system.N)).reshape(sol.shape)      # rate 0 for input genes = the zero columns
+    sol = sol.cpu().numpy()
     if expnoise > 0:
         sol = sol + rng.normal(0.0, expnoise, size=sol.shape).astype(np.float32)
     data_np = [sol[:, s].reshape(len(time_stamps), 1, system.N) for s in range(numsamples)]

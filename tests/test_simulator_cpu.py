@@ -76,3 +76,91 @@ def test_hill_rhs_and_trajectories_on_device(tmp_path):
     assert back[4] == 350 and back[5] == 5
     assert np.allclose(back[0][2], data_np[2], rtol=0, atol=1e-6) and np.array_equal(back[2][0], t_np[0])
     assert all(np.all((d >= -1e-4) & (d <= 1.0 + 1e-4)) for d in data_np)   # Hill dynamics keep expression in [0, 1]
+    # the reference's `get_derivative_instead` branch (SimulationGRN_core_init_var.R:222-240): rates at the solution's
+    # states, zeros in the input columns; same draws => same underlying states
+    ddata, _ = generate_dataset(sys_, 5, rng=np.random.default_rng(3), derivative=True)
+    want = sys_.rhs(torch.from_numpy(np.stack(data_np)).to(dev).reshape(-1, 350)).cpu().numpy().reshape(5, -1, 1, 350)
+    assert np.max(np.abs(np.stack(ddata) - want)) < 1e-6
+    assert np.all(np.stack(ddata)[..., sys_.is_input] == 0)
+
+
+# --------------------------------------------------------------------------- external inputs of a simulated data set
+def test_input_models_follow_the_reference_recipe():
+    """createInputModels (SimulationGRN_core_init_var.R:40-68): structure and ranges of the mixtures."""
+    from phoenix_amd.simulator import create_input_models
+    rng = np.random.default_rng(3)
+    names = ["g%d" % i for i in range(400)]
+    m = create_input_models(names, prop_bimodal=0.3, rng=rng)
+    nb = 0
+    for n in names:
+        k = len(m[n]["prop"])
+        assert k in (1, 2) and len(m[n]["mean"]) == k and len(m[n]["sd"]) == k
+        assert abs(m[n]["prop"].sum() - 1.0) < 1e-12
+        assert np.all(m[n]["mean"] > 0) and np.all(m[n]["mean"] < 1)
+        assert np.all(m[n]["sd"] >= 0.01) and np.all(m[n]["sd"] <= np.maximum(np.minimum(m[n]["mean"], 1 - m[n]["mean"]) / 3, 0.01))
+        if k == 2:
+            nb += 1
+            assert 0.2 <= m[n]["prop"][0] <= 0.8
+    assert 0.2 < nb / len(names) < 0.4                       # sample(c(1,2), prob = c(1-p, p))
+    low = np.mean([m[n]["mean"][0] for n in names if len(m[n]["prop"]) == 2])
+    assert 0.05 < low < 0.14                                 # Beta(10, 100) has mean 1/11
+    assert all(len(v["prop"]) == 1 for v in create_input_models(names, 0.0, rng).values())
+
+
+def test_vine_correlation_matrices_are_correlation_matrices():
+    """vineS (R:76-98): symmetric, unit diagonal, positive semi-definite; smaller beta = stronger correlations."""
+    from phoenix_amd.simulator import vine_correlation
+    rng = np.random.default_rng(0)
+    strength = {}
+    for beta in (0.5, 5.0, 50.0):
+        vals = []
+        for _ in range(5):
+            S = vine_correlation(12, beta, rng)
+            assert np.allclose(S, S.T) and np.allclose(np.diag(S), 1.0)
+            assert np.linalg.eigvalsh(S).min() > -1e-10
+            assert np.abs(S).max() <= 1.0 + 1e-12
+            vals.append(np.abs(S[np.triu_indices(12, 1)]).mean())
+        strength[beta] = np.mean(vals)
+    assert strength[0.5] > strength[5.0] > strength[50.0]
+    assert np.array_equal(vine_correlation(2, 5.0, rng), np.eye(2))
+
+
+def test_generated_inputs_keep_their_marginals_and_gain_rank_correlation():
+    """generateInputData (R:101-160): values in [0,1]; the correlation step only PERMUTES the draws of a unimodal input
+    (rank matching), never touches a bimodal one, and produces the rank correlation of the vine matrix."""
+    from phoenix_amd.simulator import create_input_models, generate_input_data
+    names = ["in%d" % i for i in range(8)]
+    models = create_input_models(names, prop_bimodal=0.4, rng=np.random.default_rng(5))
+    X0, c0 = generate_input_data(models, 4000, cor_strength=0.0, rng=np.random.default_rng(11))
+    X1, c1 = generate_input_data(models, 4000, cor_strength=0.7, rng=np.random.default_rng(11))
+    assert X0.shape == X1.shape == (4000, 8)
+    assert X0.min() >= 0 and X0.max() <= 1 and X1.min() >= 0 and X1.max() <= 1
+    assert set(c0) == set(c1) == {n for n in names if len(models[n]["prop"]) == 2}
+    for c, n in enumerate(names):
+        if n in c1:
+            assert np.array_equal(X0[:, c], X1[:, c])                        # bimodal: own draws (same generator state)
+            assert np.array_equal(c0[n], c1[n]) and set(np.unique(c1[n])) <= {1, 2}
+            lo = X1[c1[n] == 1, c].mean()
+            assert abs(lo - models[n]["mean"][0]) < 0.05
+        else:
+            assert np.array_equal(np.sort(X0[:, c]), np.sort(X1[:, c]))      # unimodal: a permutation of the same draws
+            assert abs(X1[:, c].mean() - models[n]["mean"][0]) < 0.05
+    uni = [c for c, n in enumerate(names) if n not in c1]
+    if len(uni) >= 2:
+        def spearman(a, b):
+            ra, rb = np.argsort(np.argsort(a)), np.argsort(np.argsort(b))
+            return np.corrcoef(ra, rb)[0, 1]
+        before = max(abs(spearman(X0[:, i], X0[:, j])) for i in uni for j in uni if i < j)
+        after = max(abs(spearman(X1[:, i], X1[:, j])) for i in uni for j in uni if i < j)
+        assert before < 0.08 < after
+
+
+def test_initial_states_use_the_input_models_for_input_genes():
+    from phoenix_amd.simulator import HillSystem
+    names = ["A", "B", "C", "D"]
+    exprs = ["input gene", "(0.5 * A) - (0.3 * B)", "input gene", "(0.2 * C) - (0.1 * D)"]
+    sysm = HillSystem(names, exprs, device="cpu")
+    x = sysm.sample_initial(500, rng=np.random.default_rng(1), prop_bimodal=0.0, cor_strength=0.0)
+    assert x.shape == (500, 4) and x.dtype == np.float32 and x.min() >= 0 and x.max() <= 1
+    # input genes: one truncated normal each (tight), regulated genes: Beta(2,2) + shift (wide)
+    assert x[:, 0].std() < 0.17 and x[:, 2].std() < 0.17 and x[:, 1].std() > 0.17 and x[:, 3].std() > 0.17
