@@ -14,7 +14,7 @@ import warnings
 
 import torch
 
-from . import _lib, engine
+from . import _lib, engine, generic
 from .odenet import params_of
 
 # torchdiffeq's registry (odeint.py:14-27); the engine implements the ones PHOENIX's configs use.
@@ -55,6 +55,14 @@ def _check_inputs(func, y0, t, rtol, atol, method, options):
     if torch.is_tensor(rtol) or torch.is_tensor(atol):
         rtol, atol = float(rtol), float(atol)
     return y0, t, float(rtol), float(atol), method, options
+
+
+def _is_odenet(func):
+    try:
+        params_of(func)
+        return True
+    except TypeError:
+        return False
 
 
 def _prepare(func, y0, t, options):
@@ -156,6 +164,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_
     """Forward solve only (odeint.py:30-74).  The result carries no autograd history: the reference's
     training/validation code always differentiates through `odeint_adjoint` (train_insilico.py:15-18)."""
     y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
+    if not _is_odenet(func):      # any other module: unfused torch stepper, differentiable by plain backpropagation
+        assert t.ndimension() == 1 and not return_stats, "per-sample grids / solver statistics need a PHOENIX ODENet"
+        return generic.odeint(func, y0, t, rtol, atol, method, options)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
     engine.check_pending_status()
     p = engine.params_cached(*params)
@@ -194,6 +205,15 @@ def odeint_calls(func, y0s, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None,
                    adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
     """adjoint.py:165-204.  Gradients flow to y0 and to the six ODENet parameters."""
+    if not _is_odenet(func):      # any other module: the reference's augmented system on the unfused torch stepper
+        if adjoint_options:
+            raise NotImplementedError("phoenix_amd: adjoint_options are not supported")
+        y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
+        assert t.ndimension() == 1, "per-sample time grids need a PHOENIX ODENet"
+        return generic.odeint_adjoint(func, y0, t, rtol, atol, method, options,
+                                      rtol if adjoint_rtol is None else adjoint_rtol,
+                                      atol if adjoint_atol is None else adjoint_atol,
+                                      method if adjoint_method is None else adjoint_method, adjoint_params)
     if adjoint_params is not None:
         raise NotImplementedError("phoenix_amd: adjoint_params is fixed to ODENet's six parameters")
     if adjoint_options:
