@@ -40,10 +40,11 @@ ws = engine._ws_cache[(dev.index, torch.cuda.current_stream().cuda_stream, op)]
 raw = ws[off.value: off.value + nwg.value * 16 * 8].cpu().numpy().view(np.uint64).reshape(nwg.value, 16)
 us = raw.astype(np.float64) / 100.0
 names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "quad: rest", "quad: mfma+loop", "quad: loads+act", "quad: stores", "chunk weight staging"]
-if which == "adj" and os.environ.get("PHX_ADJ") != "v1":
+second = which == "adj" and lib.phx_debug_adjoint_kernel(N, H, B, T, _lib.CTRL_PER_TRAJECTORY) == 2
+if second:
     names = ["other (between blocks)", "sweep tail P1-only", "drain+flag+publish", "reduce owned rows", "gather hidden rows", "sweep tail fused", "init(weights,y0)", "-", "norms (gather+pair sync)", "controller", "accept pass", "quadrature", "block: tile wait", "block: finish (VALU)", "block: requests+P1+P2 MFMA", "-"]
 clk = None
-if which == "adj" and os.environ.get("PHX_ADJ") != "v1":
+if second:
     clk = raw[:, 15].astype(np.float64).copy()
     us[:, 15] = 0
 tot = us.sum(1)
