@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 2
+#define PHX_ABI_VERSION 3
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -38,11 +38,15 @@ extern "C" {
 typedef struct phx_params {
     const float *Ws, *bs, *Wp, *bp, *WaT, *g;
     int N, H;
+    const void *wimg; /* optional: LDS weight images of THESE parameter values, made by phx_pack_weight_images; the solve
+                         entry points then skip their per-launch packing kernel.  NULL: packed per launch. */
 } phx_params;
 
-/* Gradient buffers with the same shapes/layouts; the engine ACCUMULATES (+=) into them. */
+/* Gradient buffers with the same shapes/layouts; the engine ACCUMULATES (+=) into them, or -- overwrite != 0 -- writes
+ * them (=): the buffers may then be uninitialised (saves the caller a zero fill). */
 typedef struct phx_grads {
     float *Ws, *bs, *Wp, *bp, *WaT, *g;
+    int overwrite;
 } phx_grads;
 
 /* torchdiffeq SOLVERS entries on the BASELINE path (odeint.py:14-27) */
@@ -87,6 +91,11 @@ int phx_device_cus(void);
 /* Workspace size (bytes) for one call of entry point `op` with this shape. */
 enum phx_op { PHX_OP_RHS_FORWARD = 0, PHX_OP_RHS_VJP = 1, PHX_OP_ODEINT = 2, PHX_OP_ADJOINT = 3 };
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T);
+/* Weight images for phx_params.wimg: the per-gene-block LDS layout of the MFMA solve kernels depends only on (N, H), so
+ * a caller that runs several solves with the same parameter values (forward + backward of a training step, a validation
+ * loop, an analysis scan) packs once.  phx_weight_image_bytes: buffer size (0: this shape has no MFMA plan). */
+size_t phx_weight_image_bytes(int N, int H);
+int phx_pack_weight_images(const phx_params *p, void *wimg, void *stream);
 /* ... for phx_odeint with opts->calls = calls (0: this batch of calls cannot be planned, solve the calls one by one) */
 size_t phx_odeint_calls_workspace_bytes(int N, int H, int B, int T, int calls);
 

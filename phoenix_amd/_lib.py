@@ -11,11 +11,12 @@ _LIB = None
 
 
 class PhxParams(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("N", C.c_int), ("H", C.c_int)]
+    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("N", C.c_int), ("H", C.c_int),
+                                                                                 ("wimg", C.c_void_p)]
 
 
 class PhxGrads(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")]
+    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("overwrite", C.c_int)]
 
 
 class PhxSolveOpts(C.Structure):
@@ -26,7 +27,7 @@ class PhxSolveOpts(C.Structure):
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
-           "phx_odeint_calls_workspace_bytes")
+           "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -76,6 +77,9 @@ def load():
     lib.phx_debug_adjoint_kernel.argtypes = [C.c_int] * 5
     lib.phx_odeint_calls_workspace_bytes.argtypes = [C.c_int] * 5
     lib.phx_odeint_calls_workspace_bytes.restype = C.c_size_t
-    assert lib.phx_abi_version() == 2
+    lib.phx_weight_image_bytes.argtypes = [C.c_int, C.c_int]
+    lib.phx_weight_image_bytes.restype = C.c_size_t
+    lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
+    assert lib.phx_abi_version() == 3
     _LIB = lib
     return lib

@@ -197,8 +197,10 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * npart, st) != hipSuccess)
             return PHX_ERR_LAUNCH;
         const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-        hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT, 1, p->H,
-                           blk_floats_ch(d1.HT, p->H));
+        if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values
+        else
+            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT, 1, p->H,
+                               blk_floats_ch(d1.HT, p->H));
         auto launch = [&](auto kern) -> int {
             const void *fn = reinterpret_cast<const void *>(kern);
             if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
@@ -219,7 +221,8 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
             const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
             const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
             hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, npart, PP, p->N, p->H,
-                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
+                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
+                               (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         }
     }

@@ -781,7 +781,7 @@ inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStre
     const long long total = 4LL * d.H * d.N + d.N + 2 * d.H;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w.dtheta, d.GB, d.PP, d.N, d.H, g->Ws, g->Wp,
-                       g->WaT, g->g, g->bs, g->bp);
+                       g->WaT, g->g, g->bs, g->bp, g->overwrite);
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
@@ -1073,7 +1073,7 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
     const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
-                       grads->WaT, grads->g, grads->bs, grads->bp);
+                       grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
@@ -1110,7 +1110,7 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
         const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
-                           grads->WaT, grads->g, grads->bs, grads->bp);
+                           grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
         if (full)
             hipLaunchKernelGGL(k2_dg_finish, dim3((p->N + 255) / 256), dim3(256), 0, st, dgp, pb.d.TG * 4, p->N, p->g,
                                grads->g);
@@ -1284,6 +1284,22 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     return need;
 }
 
+size_t phx_weight_image_bytes(int N, int H)
+{
+    if (N <= 0 || H <= 0 || H > 256 || force_v0()) return 0;
+    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC, HT = Hc <= 48 ? 3 : 8;
+    return (size_t)((N + 31) / 32) * HC * blk_floats_ch(HT, Hc) * 4;
+}
+
+int phx_pack_weight_images(const phx_params *p, void *wimg, void *stream)
+{
+    if (bad_params(p) || !wimg || phx_weight_image_bytes(p->N, p->H) == 0) return PHX_ERR_BAD_ARG;
+    const int HC = (p->H + 127) / 128, Hc = (p->H + HC - 1) / HC, HT = Hc <= 48 ? 3 : 8;
+    hipLaunchKernelGGL(k1_pack_images, dim3(((p->N + 31) / 32) * HC), dim3(256), 0, (hipStream_t)stream, to_net(p),
+                       (float *)wimg, HT, HC, Hc, blk_floats_ch(HT, Hc));
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
 size_t phx_odeint_calls_workspace_bytes(int N, int H, int B, int T, int calls)
 {
     if (N <= 0 || H <= 0 || B <= 0 || T < 0 || calls < 1 || B % calls != 0) return 0;
@@ -1394,7 +1410,7 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
             const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
             hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, pe.d.TG * pe.d.NW, PP, p->N, p->H,
-                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
+                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
             return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         }
     }
@@ -1462,12 +1478,14 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
             int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
             const Layout1 L1 = make_layout1(d1, 2 * d1.HT, false);
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
-            const W1 w1 = make_w1(workspace, L1);
+            W1 w1 = make_w1(workspace, L1);
             const size_t lds = lds_bytes_v1(d1, 0);
             // counters + granule buffers are contiguous: one fill
             if (hipMemsetAsync(w1.cnt, 0, L1.part - L1.cnt + L1.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
+            if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values
+            else
+                hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
@@ -1548,7 +1566,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
             const Layout1 L1 = make_layout1(d1, 4 * d1.HT, true, 7);
             if (workspace_bytes < L1.total) return PHX_ERR_WORKSPACE;
-            const W1 w1 = make_w1(workspace, L1);
+            W1 w1 = make_w1(workspace, L1);
             const size_t lds = lds_bytes_v1(d1, ADJ_LDS_EXTRA) + (size_t)40 * d1.Bt;
             const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
             // counters + granule buffers are contiguous: one fill
@@ -1557,7 +1575,9 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * d1.TG * d1.NW, st) != hipSuccess)
                 return PHX_ERR_LAUNCH;
             const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
-            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
+            if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values
+            else
+                hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
             if (d1.HC > 1) {
@@ -1581,7 +1601,8 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
                 hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta,
                                    /* partials of waves that own tiles (helper waves of a single small group write none) */
                                    d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW, PP, p->N,
-                                   p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp);
+                                   p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
+                                   (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
                 if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
             }
         }

@@ -72,7 +72,25 @@ class Params:
         self.g = g.detach().reshape(-1).contiguous()
         self.device = Ws.device
         self.c = _lib.PhxParams(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g),
-                                self.N, self.H)
+                                self.N, self.H, None)
+        # LDS weight images of these values, packed once here instead of once per solve launch (phx_params.wimg)
+        self.wimg = None
+        nbytes = _lib.load().phx_weight_image_bytes(self.N, self.H)
+        if nbytes:
+            self.wimg = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _check_call(_lib.load().phx_pack_weight_images(C.byref(self.c), _p(self.wimg), _stream_ptr()))
+            self.c.wimg = self.wimg.data_ptr()
+            self._wimg_stream = torch.cuda.current_stream()
+            self._wimg_event = torch.cuda.Event()
+            self._wimg_event.record()
+
+    def on_current_stream(self):
+        """a solve on another stream than the one that packed the images waits for the packing"""
+        if self.wimg is not None:
+            cur = torch.cuda.current_stream()
+            if cur != self._wimg_stream:
+                cur.wait_event(self._wimg_event)
+        return self
 
     def new_grads(self):
         return Grads(self)
@@ -98,17 +116,17 @@ def params_cached(Ws, bs, Wp, bp, Wa, g):
 
 
 class Grads:
-    """One flat zero-initialised buffer carved into the six gradient tensors (the engine accumulates into them);
-    `flat` is also what a data-parallel all-reduce wants."""
+    """One flat buffer carved into the six gradient tensors.  It is NOT zero-filled: the engine call it is handed to
+    writes every element (`phx_grads.overwrite`)."""
 
     def __init__(self, p):
         H, N = p.H, p.N
         sizes = (H * N, H, H * N, H, 2 * H * N, N)
-        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=p.device)
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=p.device)
         parts = torch.split(self.flat, sizes)
         self.Ws, self.bs, self.Wp, self.bp = parts[0].view(H, N), parts[1], parts[2].view(H, N), parts[3]
         self.WaT, self.g = parts[4].view(2 * H, N), parts[5]
-        self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g))
+        self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g), 1)
 
     def as_reference_layout(self, g_shape):
         """(Ws, bs, Wp, bp, Wa[N,2H], g[1,N]) gradients in the reference's parameter layouts"""
@@ -149,9 +167,14 @@ def status_mode():
     return _status_mode
 
 
+_free_host = {}        # (shape, dtype) -> pinned buffers of checked solves, reused (no pinned allocation in steady state)
+
+
 def defer_status(status):
     """queue a device status block [L, B] (or [B]) for a later check"""
-    host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+    key = (tuple(status.shape), status.dtype)
+    pool = _free_host.setdefault(key, [])
+    host = pool.pop() if pool else torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
     host.copy_(status, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -167,6 +190,9 @@ def check_pending_status(wait=False):
         if wait:
             ev.synchronize()
         _pending.pop(0)
+        pool = _free_host.setdefault((tuple(host.shape), host.dtype), [])
+        if len(pool) < 8:
+            pool.append(host)
         raise_for_status(host)
 
 
@@ -249,6 +275,7 @@ def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f3
     sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
     if stats is None:
         stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device, calls)
     o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls)
     _check_call(_lib.load().phx_odeint(C.byref(p.c), _p(y0), _p(t64), B, T, C.byref(o), _p(sol), _p(stats[0]),
@@ -264,6 +291,7 @@ def solve_adjoint(p, t64, y_saved, grad_y, method, control, rtol, atol, t_per_sa
     if stats is None:
         stats = torch.zeros((3, B), dtype=torch.int32, device=y_saved.device)
     grads = p.new_grads() if want_grads else None
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ADJOINT, p.N, p.H, B, T, y_saved.device)
     o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps)
     _check_call(_lib.load().phx_odeint_adjoint_backward(
