@@ -961,6 +961,20 @@ def test_odeint_calls_equals_separate_calls(pa, dev, oracle, N, H, B, K, method)
             pa.odeint_calls(net, y0d, torch.tensor([0.0, 40.0], device=dev), options={"max_num_steps": 1})
 
 
+def test_odeint_calls_without_a_batched_plan_runs_the_calls_one_by_one(pa, dev, monkeypatch):
+    """shapes the MFMA planner does not take (here: the VALU engine forced) have no calls-per-launch plan: the same
+    answer, one launch per call"""
+    p = rand_params(64, 8, seed=2)
+    net = make_net(pa, dev, p)
+    y0s = torch.rand(3, 5, 1, 64, device=dev) - 0.25
+    t = torch.from_numpy(np.arange(0, 1, 0.25)).to(dev)
+    ref = pa.odeint_calls(net, y0s, t)
+    monkeypatch.setenv("PHX_ENGINE", "v0")
+    got = pa.odeint_calls(net, y0s, t)
+    assert got.shape == ref.shape == (3, 4, 5, 1, 64)
+    assert relerr(got.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+
+
 def test_f3_calculate_trajectory(pa, dev):
     """DataHandler.calculate_trajectory (datahandler.py:310-340): same samples (numpy stream) and the same 300-point
     dense trajectories as the reference, all samples integrated in one launch."""
