@@ -139,6 +139,12 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t, int B, int
  * `read_prior_matrix(..., sparse=True)` materialises (train_insilico.py:64-73).  out [K,N] is overwritten. */
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out,
                       int K, int N, void *stream);
+/* The same product with P in sliced-ELL form (the fast path; phoenix_amd.prior builds it once per prior matrix):
+ * columns in slices of 64; width[s] = longest column of slice s; entry i of column 64 s + l at sptr[s] + i*64 + l in
+ * ridx / vals (rows ascending inside a column, padding row 0 / value 0).  X rows are staged in LDS, so N*4 bytes must
+ * fit it (PHX_ERR_BAD_ARG otherwise: use phx_prior_targets). */
+int phx_prior_targets_sell(const long long *sptr, const int *width, const int *ridx, const float *vals, const float *X,
+                           float *out, int K, int N, void *stream);
 
 /* Fused head of the prior branch of training_step (train_insilico.py:134-135):
  *   loss[0] = mean((prior_only_forward(X) - target)^2)  over B*N elements   (device float)

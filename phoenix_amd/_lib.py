@@ -27,7 +27,7 @@ class PhxSolveOpts(C.Structure):
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
-           "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images")
+           "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -69,6 +69,7 @@ def load():
     lib.phx_odeint_adjoint_backward.argtypes = [C.POINTER(PhxParams), vp, C.c_int, C.c_int, C.POINTER(PhxSolveOpts),
                                                 vp, vp, vp, C.POINTER(PhxGrads), vp, vp, vp, vp, C.c_size_t, vp]
     lib.phx_prior_targets.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.phx_prior_targets_sell.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.phx_prior_mse.argtypes = [C.POINTER(PhxParams), vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp]
     lib.phx_hill_rhs.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.phx_hill_simulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, C.c_int, vp]

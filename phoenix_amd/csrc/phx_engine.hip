@@ -1217,6 +1217,30 @@ int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, c
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
+int phx_prior_targets_sell(const long long *sptr, const int *width, const int *ridx, const float *vals, const float *X,
+                           float *out, int K, int N, void *stream)
+{
+    if (!sptr || !width || !ridx || !vals || !X || !out || K <= 0 || N <= 0) return PHX_ERR_BAD_ARG;
+    const int nslices = (N + 63) / 64;
+    const size_t rowbytes = (size_t)N * 4;
+    const int RT = (int)std::min<size_t>(4, LDS_BUDGET / rowbytes);
+    if (RT < 1) return PHX_ERR_BAD_ARG;   // a row of X does not fit LDS: use phx_prior_targets
+    const int grid = std::max(1, std::min((K + RT - 1) / RT, 4 * std::max(1, num_cus())));
+    const size_t lds = (size_t)RT * rowbytes;
+    hipStream_t st = (hipStream_t)stream;
+    auto go = [&](auto kern) -> int {
+        if (!set_lds_fn(reinterpret_cast<const void *>(kern), lds)) return PHX_ERR_LAUNCH;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, sptr, width, ridx, vals, X, out, K, N, nslices);
+        return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+    };
+    switch (RT) {
+        case 1: return go(k_prior_spmm_sell<1>);
+        case 2: return go(k_prior_spmm_sell<2>);
+        case 3: return go(k_prior_spmm_sell<3>);
+        default: return go(k_prior_spmm_sell<4>);
+    }
+}
+
 void phx_debug_set_kernel_events(void *ev_start, void *ev_stop)
 {
     g_ev_start = (hipEvent_t)ev_start;

@@ -36,12 +36,35 @@ class PriorMatrix:
         self.rowidx = torch.from_numpy(rows.astype(np.int32)).to(device)
         self.vals = torch.from_numpy(vals).to(device)
         self.device = torch.device(device)
+        self._build_sell(rows, cols, vals, np.cumsum(colptr))
+
+    def _build_sell(self, rows, cols, vals, colptr):
+        """sliced-ELL copy for phx_prior_targets_sell: slices of 64 columns, entry i of column 64 s + l at
+        sptr[s] + 64 i + l (rows ascending inside a column, padding row 0 / value 0)"""
+        N = self.N
+        ns = (N + 63) // 64
+        lens = np.zeros(ns * 64, np.int64)
+        lens[:N] = np.diff(colptr)
+        width = lens.reshape(ns, 64).max(axis=1)
+        sptr = np.concatenate([[0], np.cumsum(width * 64)])
+        ridx = np.zeros(int(sptr[-1]), np.int32)
+        v = np.zeros(int(sptr[-1]), np.float32)
+        if len(vals):
+            i_in_col = np.arange(len(vals)) - colptr[cols]          # position inside its column (rows are ascending)
+            dst = sptr[cols // 64] + i_in_col * 64 + (cols % 64)
+            ridx[dst] = rows
+            v[dst] = vals
+        self.sell_ptr = torch.from_numpy(sptr[:-1].astype(np.int64)).to(self.device)
+        self.sell_width = torch.from_numpy(width.astype(np.int32)).to(self.device)
+        self.sell_rows = torch.from_numpy(ridx).to(self.device)
+        self.sell_vals = torch.from_numpy(v).to(self.device)
 
     def abs(self):
         """`torch.abs(prior_mat)` of the real-data drivers (train_breast.py:264-265, train_yeast.py:263)"""
         out = object.__new__(PriorMatrix)
         out.__dict__.update(self.__dict__)
         out.vals = self.vals.abs()
+        out.sell_vals = self.sell_vals.abs()
         return out
 
     def to_dense(self):
@@ -75,7 +98,12 @@ def prior_targets(batch_for_prior, prior):
         raise ValueError("last dimension %d != number of genes %d" % (X.shape[-1], N))
     X2 = X.detach().reshape(-1, N).contiguous()
     out = torch.empty_like(X2)
-    rc = _lib.load().phx_prior_targets(engine._p(prior.colptr), engine._p(prior.rowidx), engine._p(prior.vals),
-                                       engine._p(X2), engine._p(out), X2.shape[0], N, engine._stream_ptr())
+    lib = _lib.load()
+    rc = lib.phx_prior_targets_sell(engine._p(prior.sell_ptr), engine._p(prior.sell_width), engine._p(prior.sell_rows),
+                                    engine._p(prior.sell_vals), engine._p(X2), engine._p(out), X2.shape[0], N,
+                                    engine._stream_ptr())
+    if rc == 4:      # a row of X does not fit LDS (N > ~40 000): the plain CSC kernel
+        rc = lib.phx_prior_targets(engine._p(prior.colptr), engine._p(prior.rowidx), engine._p(prior.vals),
+                                   engine._p(X2), engine._p(out), X2.shape[0], N, engine._stream_ptr())
     engine._check_call(rc)
     return out.reshape(X.shape)
