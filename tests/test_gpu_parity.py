@@ -1038,3 +1038,40 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
         assert relerr(res[eng][1], res["v0"][1]) < gtol, (eng,) + what
         for k in KEYS:
             assert relerr(res[eng][2][k], res["v0"][2][k]) < gtol, (eng, k) + what
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_new_paths_agree_with_their_references(pa, dev, monkeypatch, seed):
+    """Fuzz of the round-2 paths on random shapes: (1) batched odeint calls against the separate calls, (2) the full-VJP
+    kernel chain against the VALU engine.  Engine vs engine -- an extra on top of the oracle-checked cases above."""
+    from phoenix_amd import engine
+    rs = np.random.RandomState(1000 + seed)
+    N = int(rs.choice([33, 64, 97, 350, 513, 1200, 2111]))
+    H = int(rs.choice([3, 8, 17, 40, 48, 49, 100, 128]))
+    p = rand_params(N, H, seed=seed, std=0.5 / np.sqrt(N))
+    net = make_net(pa, dev, p)
+    # (1)
+    K, B = int(rs.randint(2, 7)), int(rs.randint(1, 40))
+    method = str(rs.choice(["dopri5", "rk4", "euler", "midpoint"]))
+    T = int(rs.randint(2, 6))
+    t = torch.from_numpy(np.sort(rs.rand(T)) * (1 if rs.rand() < 0.7 else -1)).to(dev)
+    y0s = torch.from_numpy((rs.rand(K, B, 1, N).astype(np.float32) - 0.5) * rs.uniform(0.2, 1.5, size=(K, 1, 1, 1)).astype(np.float32)).to(dev)
+    out = pa.odeint_calls(net, y0s, t, method=method)
+    for k in range(K):
+        one = pa.odeint(net, y0s[k], t, method=method)
+        assert relerr(out[k].cpu().numpy(), one.cpu().numpy()) < 1e-5, (N, H, K, B, method, k)
+    # (2)
+    if H <= 128:
+        P = engine.params_cached(*pa.odenet.params_of(net))
+        Bv = int(rs.randint(1, 200))
+        y = torch.from_numpy((rs.rand(Bv, N) * 3 - 1).astype(np.float32)).to(dev)
+        cot = torch.from_numpy(rs.randn(Bv, N).astype(np.float32)).to(dev)
+        po = bool(rs.rand() < 0.3)
+        vjp, grads = engine.rhs_vjp(P, y, cot, prior_only=po)
+        monkeypatch.setenv("PHX_ENGINE", "v0")
+        vjp0, grads0 = engine.rhs_vjp(P, y, cot, prior_only=po)
+        monkeypatch.delenv("PHX_ENGINE")
+        assert relerr(vjp.cpu().numpy(), vjp0.cpu().numpy()) < TOL_RHS, (N, H, Bv, po)
+        for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+            a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
+            assert (np.abs(b).max() == 0 and np.abs(a).max() == 0) or relerr(a, b) < 2 * TOL_RHS, (k, N, H, Bv, po)
