@@ -40,6 +40,12 @@ def test_null_arguments_are_rejected_without_a_gpu():
     from phoenix_amd import _lib
     lib = _lib.load()
     assert lib.phx_rhs_forward(None, None, None, 1, 0, None, 0, None) == 4  # PHX_ERR_BAD_ARG
+    assert lib.phx_pack_weight_images(None, None, None) == 4
+    assert lib.phx_prior_targets_sell(None, None, None, None, None, None, 1, 1, None) == 4
+    # weight images: a pure function of (N, H); 0 where no MFMA plan exists
+    a, b = lib.phx_weight_image_bytes(350, 40), lib.phx_weight_image_bytes(11165, 40)
+    assert 0 < a < b and lib.phx_weight_image_bytes(11165, 200) > b and lib.phx_weight_image_bytes(0, 40) == 0
+    assert lib.phx_odeint_calls_workspace_bytes(350, 40, 60, 10, 7) == 0          # 60 rows are not 7 equal calls
 
 
 def test_no_cpu_fallback():
