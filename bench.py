@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--status", default="deferred", choices=["deferred", "immediate"],
                     help="solver status read-back: behind the backward kernel (checked at a later engine call) or a "
                          "blocking round trip at the end of every backward()")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="diagnostic, single process only: with --scaling strong, integrate rank 0's shard of a run with "
+                         "this many ranks (what ONE GPU of that run would do per step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,7 +211,7 @@ def main():
         # the SAME 256-trajectory problem at every world size, sharded over the ranks (contiguous chunks)
         from phoenix_amd import parallel
         net, y0, t = make_problem(wl, device, seed=0)
-        lo, hi = parallel.shard_range(B, rank, world)
+        lo, hi = parallel.shard_range(B, rank, world if world > 1 or not args.shard_of else args.shard_of)
         y0, t = y0[lo:hi].contiguous(), t[lo:hi].contiguous()
         B_global, B = B, hi - lo
     else:
