@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-segment time of the v1 persistent kernels (PHX_PROF=1), averaged over workgroups.
-usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj]"""
+usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj] [trajectories]"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,9 @@ os.environ["PHX_PROF"] = "1"
 import bench  # noqa: E402
 from phoenix_amd import _lib, engine  # noqa: E402
 
-wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "breast"]
+wl = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "breast"])
+if len(sys.argv) > 3:
+    wl["B"] = int(sys.argv[3])
 which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
 dev = torch.device("cuda:0")
 net, y0, t = bench.make_problem(wl, dev, 0)
