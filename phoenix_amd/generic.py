@@ -6,8 +6,9 @@ interval, solvers.py:77-95, fixed_grid.py, rk_common.py:96-103; dopri5 with the 
 ratio, step-size rule and quartic dense output, rk_common.py:39-228, misc.py:47-103, interp.py), one batch-wide step
 controller like the reference's `odeint`, every operation a torch op (so `odeint` is differentiable by plain
 backpropagation, as the reference's is, and `odeint_adjoint` integrates the augmented system of adjoint.py:32-162 with
-`torch.autograd.grad` supplying the vector-Jacobian products).  Nothing here is a CPU fallback of the engine: tensors
-stay where the caller put them and no engine kernel is replaced.
+`torch.autograd.grad` supplying the vector-Jacobian products).  Nothing here is a fallback of the engine: an ODENet never
+reaches this module, no engine kernel is replaced, and like every other entry point of the package it takes device
+tensors only (phoenix_amd.odeint raises for host tensors before calling in).
 """
 import torch
 

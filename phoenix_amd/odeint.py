@@ -165,6 +165,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_
     training/validation code always differentiates through `odeint_adjoint` (train_insilico.py:15-18)."""
     y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
     if not _is_odenet(func):      # any other module: unfused torch stepper, differentiable by plain backpropagation
+        engine._require_gpu(y0, "y0")          # like every other entry point: no CPU compute path in this package
         assert t.ndimension() == 1 and not return_stats, "per-sample grids / solver statistics need a PHOENIX ODENet"
         return generic.odeint(func, y0, t, rtol, atol, method, options)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
@@ -209,6 +210,7 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
         if adjoint_options:
             raise NotImplementedError("phoenix_amd: adjoint_options are not supported")
         y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
+        engine._require_gpu(y0, "y0")          # like every other entry point: no CPU compute path in this package
         assert t.ndimension() == 1, "per-sample time grids need a PHOENIX ODENet"
         return generic.odeint_adjoint(func, y0, t, rtol, atol, method, options,
                                       rtol if adjoint_rtol is None else adjoint_rtol,

@@ -71,12 +71,13 @@ def test_argument_errors_match_reference():
         phoenix_amd.odeint(net, torch.zeros(1, 16, dtype=torch.int64), t)
     with pytest.raises(NotImplementedError):
         phoenix_amd.odeint(net, y0, t, method="bosh3")
-    # a module that is not a PHOENIX ODENet is integrated by the unfused torch stepper (tests/test_generic_cpu.py); the
+    # a module that is not a PHOENIX ODENet is integrated by the unfused torch stepper (tests/test_generic_gpu.py); the
     # engine-level recognition still says what it wants
     with pytest.raises(TypeError, match="ODENet only"):
         phoenix_amd.odenet.params_of(torch.nn.Linear(16, 16))
     lin = torch.nn.Linear(16, 16)
-    assert phoenix_amd.odeint(lambda tt, y: lin(y), y0, t, method="euler").shape == (2, 1, 16)
+    with pytest.raises(RuntimeError, match="no CPU path|must live on the GPU"):     # device tensors only, whatever the func
+        phoenix_amd.odeint(lambda tt, y: lin(y), y0, t, method="euler")
 
 
 def test_odenet_mirror_has_reference_structure():
