@@ -193,8 +193,11 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * (d1.NW / 2);   // pairs that own tiles
         // counters + granule buffers are contiguous: one fill
         if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
-        // the quadrature first-touches every element of every partial (plain stores) when T >= 2
-        if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * npart, st) != hipSuccess)
+        // The quadrature first-touches every element of a pair's partial (plain stores) -- but only pairs that own at
+        // least one real trajectory ever run it: with several groups the last group's trailing pairs can hold padding
+        // tiles only (their controllers start "done"), with T < 2 nobody steps, and a pair whose trajectories all
+        // failed at once never gets there either.  Every partial must read as zero then: always cleared (a few us).
+        if (grads && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * npart, st) != hipSuccess)
             return PHX_ERR_LAUNCH;
         const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
         if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values

@@ -1075,3 +1075,58 @@ def test_random_shapes_new_paths_agree_with_their_references(pa, dev, monkeypatc
         for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
             a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
             assert (np.abs(b).max() == 0 and np.abs(a).max() == 0) or relerr(a, b) < 2 * TOL_RHS, (k, N, H, Bv, po)
+
+
+@pytest.mark.parametrize("N,H,B,method", [(350, 40, 1500, "rk4"), (350, 40, 1000, "dopri5"), (2000, 120, 200, "dopri5"),
+                                          (700, 20, 40, "dopri5"), (1200, 100, 300, "rk4")])
+def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkeypatch, N, H, B, method):
+    """Every call must initialise whatever it reads from the caller's workspace.  The batch sizes leave padding-only
+    wave pairs in the last batch group of the second backward kernel (their gradient partials are never written by the
+    kernel: a stale partial of an earlier launch used to be summed into the gradients).  Each operation runs on a
+    workspace filled with zeros and on one filled with 1000.0 -- bitwise equal outputs, for every backward kernel --
+    and the default kernel's gradients agree with the first-generation kernel's."""
+    from phoenix_amd import engine, _lib
+    p = rand_params(N, H, seed=N + B, std=0.5 / np.sqrt(N))
+    net = make_net(pa, dev, p)
+    P = engine.params_cached(*pa.odenet.params_of(net))
+    rs = np.random.RandomState(B)
+    y0 = torch.from_numpy((rs.rand(B, N) * 0.8 + 0.1).astype(np.float32)).to(dev)
+    t = torch.stack([torch.zeros(B), torch.full((B,), 0.05)], 1).double().to(dev)
+    G = torch.from_numpy((rs.randn(2, B, N) / (B * N)).astype(np.float32)).to(dev)
+    cot = torch.from_numpy(rs.randn(B, N).astype(np.float32)).to(dev)
+
+    def poison(value):
+        for buf in engine._ws_cache.values():
+            buf.view(torch.float32)[: buf.numel() // 4].fill_(value)
+
+    def everything():
+        out = []
+        sol, st, _, _ = engine.solve_forward(P, y0, t, method, _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, 0)
+        adj, grads, st2, _, _ = engine.solve_adjoint(P, t, sol, G, method, _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, 0)
+        assert int(st.max()) == 0 and int(st2.max()) == 0
+        out += [sol, adj, grads.flat]
+        vjp, g2 = engine.rhs_vjp(P, y0, cot)
+        out += [vjp, g2.flat, engine.rhs_forward(P, y0)]
+        _, g3 = engine.rhs_vjp(P, y0, cot, prior_only=True, want_vjp_y=False)      # the prior branch's backward chain
+        out += [g3.flat, engine.rhs_forward(P, y0, prior_only=True)]
+        pm = engine.prior_mse(P, y0, cot)                                          # fused loss head (large batches only)
+        if pm is not None:
+            out += [pm[0], pm[1]]
+        return [x.clone() for x in out]
+
+    results = {}
+    for variant, env in (("default", {}), ("first kernel", {"PHX_ADJ": "v1"})):
+        for k in ("PHX_ADJ", "PHX_ADJ2_NP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        everything()                       # allocates the workspaces of this variant
+        poison(0.0)
+        clean = everything()
+        poison(1000.0)
+        dirty = everything()
+        for a, b in zip(clean, dirty):
+            assert torch.equal(a, b), variant
+        results[variant] = clean
+    for a, b in zip(results["default"][1:3], results["first kernel"][1:3]):      # adj_y0 and the six gradients
+        assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
