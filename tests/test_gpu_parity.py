@@ -743,10 +743,14 @@ def test_chunked_hidden_layer_shared_control_vs_oracle(pa, dev, oracle, N, H, B,
         if engine == "v0":
             os.environ["PHX_ENGINE"] = "v0"
         try:
-            zero_grads(net)
-            y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
-            sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
-            (sol * torch.from_numpy(G).to(dev)).sum().backward()
+            for rep in range(2):     # the second pass runs on workspaces that exist and were filled with junk
+                from phoenix_amd import engine as _eng
+                for buf in _eng._ws_cache.values():
+                    buf.view(torch.float32)[: buf.numel() // 4].fill_(777.0)
+                zero_grads(net)
+                y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+                sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
+                (sol * torch.from_numpy(G).to(dev)).sum().backward()
         finally:
             os.environ.pop("PHX_ENGINE", None)
         assert relerr(sol.detach().cpu().numpy(), ref) < tol, engine
@@ -1002,7 +1006,7 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
     r = np.random.RandomState(1000 + seed)
     N = int(r.choice([33, 96, 350, 777, 1500]))
     H = int(r.choice([5, 24, 40, 64, 120, 150]))
-    B = int(r.choice([1, 3, 17, 40, 70]))
+    B = int(r.choice([1, 3, 17, 40, 70, 130, 200, 330]))   # the larger ones: several batch groups, padding-only waves
     method = str(r.choice(["dopri5", "rk4", "midpoint", "euler"]))
     T = int(r.choice([2, 3, 5]))
     per_sample = bool(r.rand() < 0.5)
@@ -1023,10 +1027,14 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
         if eng == "alt":
             os.environ.update(alt)
         try:
-            zero_grads(net)
-            y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
-            sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
-            (sol * torch.from_numpy(G).to(dev)).sum().backward()
+            for rep in range(2):     # the second pass runs on workspaces that exist and were filled with junk
+                from phoenix_amd import engine as _eng
+                for buf in _eng._ws_cache.values():
+                    buf.view(torch.float32)[: buf.numel() // 4].fill_(777.0)
+                zero_grads(net)
+                y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+                sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
+                (sol * torch.from_numpy(G).to(dev)).sum().backward()
         finally:
             for k in ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP"):
                 os.environ.pop(k, None)
