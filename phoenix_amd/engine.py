@@ -115,6 +115,13 @@ def params_cached(Ws, bs, Wp, bp, Wa, g):
     return p
 
 
+def invalidate_params():
+    """forget the cached engine-layout copies of parameters.  Needed only after writing a parameter through a view that
+    does not bump its version counter (`p.data.copy_(...)`, a raw pointer): optimizers, `copy_`, `add_` under
+    `no_grad`, `load_state_dict` all bump it and need nothing."""
+    _params_cache.clear()
+
+
 class Grads:
     """One flat buffer carved into the six gradient tensors.  It is NOT zero-filled: the engine call it is handed to
     writes every element (`phx_grads.overwrite`)."""
