@@ -225,6 +225,42 @@ def test_g5_training_step(pa, dev, method, lam):
         assert d.size == 0 or d.max() < 1e-5, k
 
 
+def test_parameter_cache_follows_the_optimizer(pa, dev):
+    """The engine caches its layout of the parameters (transposed W_alpha, packed LDS weight images) per parameter
+    version.  Five SGD steps of the reference's training_step with the cache, and the same five steps with the cache
+    dropped before every engine call, must take the network to bitwise the same parameters -- including a validation
+    solve between steps (no_grad, same weights: a cache hit) and a `load_state_dict` in the middle."""
+    from phoenix_amd import engine
+    g = sub(load_golden("g5_training_step"), "dopri5/lam0.99/")
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    h = _Handler(T("batch"), T("t"), T("target"))
+
+    def train(drop_cache):
+        net = make_net(pa, dev, sub(g, "p_"))
+        opt = torch.optim.SGD(net.parameters(), lr=0.05)
+        snapshot = None
+        vals = []
+        for step in range(5):
+            if drop_cache:
+                engine.invalidate_params()
+            pa.training_step(net, h, opt, "dopri5", 4, False, False, T("X"), T("prior_grad"), 0.99)
+            if drop_cache:
+                engine.invalidate_params()
+            with torch.no_grad():
+                vals.append(pa.odeint_adjoint(net, h.b[0], h.b[1], method="dopri5")[1].clone())
+            if step == 1:
+                snapshot = {k: v.clone() for k, v in net.state_dict().items()}
+            if step == 3:
+                net.load_state_dict(snapshot)          # back to the weights after step 2
+        return [p.detach().clone() for p in net.parameters()], vals
+
+    p1, v1 = train(False)
+    p2, v2 = train(True)
+    for a, b in zip(p1 + v1, p2 + v2):
+        assert torch.equal(a, b)
+    assert not torch.equal(v1[0], v1[1])               # the weights did move between the validation solves
+
+
 @pytest.mark.parametrize("name", ["yeast", "breast"])
 def test_g7_realdata(pa, dev, name):
     g = sub(load_golden("g7_realdata"), name + "/")
