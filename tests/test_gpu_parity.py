@@ -1174,3 +1174,36 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
         results[variant] = clean
     for a, b in zip(results["default"][1:3], results["first kernel"][1:3]):      # adj_y0 and the six gradients
         assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
+def test_other_stream_and_mixed_time_directions(pa, dev, oracle):
+    """(1) A solve issued on a side stream right after the parameters were laid out on the default stream (the weight
+    images are packed there) waits for that packing.  (2) In the per-sample loop every sample has its own time grid --
+    also its own DIRECTION: half of the batch integrates backwards in time here.  Both against the oracle."""
+    N, H, B = 350, 30, 6
+    p = rand_params(N, H, seed=12, std=0.6 / np.sqrt(N))
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    rs = np.random.RandomState(5)
+    y0 = (rs.rand(B, 1, N).astype(np.float32) - 0.25)
+    t = np.stack([np.array([0.0, 0.3, 0.7]) if b % 2 == 0 else np.array([1.0, 0.6, 0.1]) for b in range(B)])
+    G = rs.randn(3, B, 1, N).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+    side = torch.cuda.Stream(device=dev)
+    y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
+    tt, Gt = torch.from_numpy(t).to(dev), torch.from_numpy(G).to(dev)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        net.gene_multipliers.mul_(1.0)            # new parameter version: the next call lays the parameters out again
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sol = pa.odeint_adjoint(net, y0t, tt)
+        (sol * Gt).sum().backward()
+    side.synchronize()
+    got_sol = sol.detach().cpu().numpy().reshape(3, B, N).transpose(1, 0, 2)          # oracle layout [B,T,N]
+    assert relerr(got_sol, ref) < TOL_DOPRI
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G.reshape(3, B, N).transpose(1, 0, 2).copy(),
+                                                         method="dopri5")[:2]
+    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), np.asarray(adj_ref).reshape(B, N)) < TOL_DOPRI_GRAD
+    got = grads_of(net)
+    for k in KEYS:
+        assert relerr(got[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
