@@ -1156,6 +1156,11 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
         pm = engine.prior_mse(P, y0, cot)                                          # fused loss head (large batches only)
         if pm is not None:
             out += [pm[0], pm[1]]
+        with torch.no_grad():                                                      # shared step control, batched calls
+            ts = torch.from_numpy(np.arange(0, 0.5, 0.1)).to(dev)
+            nb = min(B, 90) // 3
+            out += [pa.odeint(net, y0[:37].unsqueeze(1), ts, method=method),
+                    pa.odeint_calls(net, y0[:3 * nb].reshape(3, nb, 1, N), ts, method=method)]
         return [x.clone() for x in out]
 
     results = {}
