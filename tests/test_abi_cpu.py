@@ -91,3 +91,24 @@ def test_odenet_mirror_has_reference_structure():
     assert net.gene_multipliers.shape == (1, 30)
     w = net.net_sums.linear_out.weight
     assert (w == 0).float().mean() >= 0.9   # nn.init.sparse_(sparsity=0.95)
+
+
+def test_checkpoint_round_trip_in_the_references_four_file_format(tmp_path):
+    """ODENet.save / load_model (odenet.py:100-133): four pickles `<name>_{prods,sums,alpha_comb,gene_multipliers}.pt`;
+    a fresh network that loads them has identical parameters in the reference's parameters() order."""
+    import phoenix_amd
+    torch.manual_seed(3)
+    a = phoenix_amd.ODENet("cpu", 21, neurons=6)
+    with torch.no_grad():                     # the 95 %-sparse init leaves a 6-row layer all zero: give it content
+        for prm in a.parameters():
+            prm.add_(torch.randn_like(prm))
+    fp = str(tmp_path / "model.pt")
+    a.save(fp)
+    for suffix in ("_prods", "_sums", "_alpha_comb", "_gene_multipliers"):
+        assert os.path.exists(str(tmp_path / ("model" + suffix + ".pt")))
+    torch.manual_seed(4)
+    b = phoenix_amd.ODENet("cpu", 21, neurons=6)
+    assert not torch.equal(a.net_sums.linear_out.weight, b.net_sums.linear_out.weight)
+    b.load(fp)
+    for (na, pa_), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa_, pb)
