@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 3
+#define PHX_ABI_VERSION 4
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -176,8 +176,10 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
                              int *n_workgroups, int *plan);
 /* Diagnostic only: which backward-solve kernel phx_odeint_adjoint_backward launches for this shape:
  * 0 = k_solve_adj (VALU, grid barriers), 1 = k1_solve_adj (MFMA, one wave per trajectory tile),
- * 2 = k1_solve_adj2 (MFMA, wave pairs, fused sweeps).  bench.py keys its profile lookups with it. */
+ * 2 = k1_solve_adj2 (MFMA, wave pairs, fused sweeps), 3 = k1_solve_adj3 (MFMA, dopri5 with H <= 48: fused sweeps over
+ * a 16-vector private state).  bench.py keys its profile lookups with it.  The first form assumes dopri5. */
 int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control);
+int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int method);
 
 #ifdef __cplusplus
 }

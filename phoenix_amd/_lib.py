@@ -27,7 +27,8 @@ class PhxSolveOpts(C.Structure):
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
-           "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell")
+           "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell",
+           "phx_debug_adjoint_kernel_m")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -76,11 +77,12 @@ def load():
     lib.phx_debug_set_kernel_events.argtypes = [vp, vp]
     lib.phx_debug_set_kernel_events.restype = None
     lib.phx_debug_adjoint_kernel.argtypes = [C.c_int] * 5
+    lib.phx_debug_adjoint_kernel_m.argtypes = [C.c_int] * 6
     lib.phx_odeint_calls_workspace_bytes.argtypes = [C.c_int] * 5
     lib.phx_odeint_calls_workspace_bytes.restype = C.c_size_t
     lib.phx_weight_image_bytes.argtypes = [C.c_int, C.c_int]
     lib.phx_weight_image_bytes.restype = C.c_size_t
     lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
-    assert lib.phx_abi_version() == 3
+    assert lib.phx_abi_version() == 4
     _LIB = lib
     return lib

@@ -1253,6 +1253,7 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     D1 d1;
     if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
     const bool adj = op == PHX_OP_ADJOINT;
+    if (adj && adj3_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (adj && adj2_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1, adj ? 40 : 0,
                  adj ? ADJ_NW_CAP : 8))
@@ -1266,6 +1267,12 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
 
 int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control)
 {
+    return phx_debug_adjoint_kernel_m(N, H, B, T, control, PHX_DOPRI5);
+}
+
+int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int method)
+{
+    if (adj3_chunk(N, H, B, T, control, method) > 0) return 3;
     if (adj2_chunk(N, H, B, T, control) > 0) return 2;
     return pick_chunk_v1(N, H, B, T, control, true) > 0 ? 1 : 0;
 }
@@ -1298,6 +1305,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     }
     if (op == PHX_OP_ADJOINT) {
         need = std::max(need, adj2_workspace_bytes(N, H, B, T));
+        need = std::max(need, adj3_workspace_bytes(N, H, B, T));
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl) {
             const int bc = pick_chunk_v1(N, H, B, T, ctl, true);
@@ -1570,6 +1578,10 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
     cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
     cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
     cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    // third kernel (dopri5, narrow hidden layer exchanged among many gene tiles: the breast-cancer shape; phx_adj3.hip)
+    if (adj3_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
+        return adj3_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,
+                        workspace, workspace_bytes, st);
     // second-generation MFMA kernel (wave pairs, fused sweeps): hidden layers that stay LDS resident (phx_adj2.hip)
     if (adj2_chunk(p->N, p->H, B, T, o->control) > 0)
         return adj2_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,

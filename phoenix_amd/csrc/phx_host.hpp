@@ -113,3 +113,13 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
              const float *grad_y_all, float *adj_y0_all, const phx_grads *grads, int *status_all, int *nfe_all,
              int *nsteps_all, void *workspace, size_t workspace_bytes, hipStream_t st);
 }  // namespace phxh
+
+// ---- third backward kernel (phx_adj3.hip: dopri5, H <= 48, fused sweeps over a 16-vector private state)
+namespace phxh {
+int adj3_chunk(int N, int H, int B, int T, int control, int method);
+size_t adj3_workspace_bytes(int N, int H, int B, int T);   // max over the control modes (0 when unplanned)
+int adj3_profile_region(int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups, int *plan6);
+int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_solve_opts *o, const float *y_saved_all,
+             const float *grad_y_all, float *adj_y0_all, const phx_grads *grads, int *status_all, int *nfe_all,
+             int *nsteps_all, void *workspace, size_t workspace_bytes, hipStream_t st);
+}  // namespace phxh

@@ -42,7 +42,12 @@ ws = engine._ws_cache[(dev.index, torch.cuda.current_stream().cuda_stream, op)]
 raw = ws[off.value: off.value + nwg.value * 16 * 8].cpu().numpy().view(np.uint64).reshape(nwg.value, 16)
 us = raw.astype(np.float64) / 100.0
 names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "quad: rest", "quad: mfma+loop", "quad: loads+act", "quad: stores", "chunk weight staging"]
-second = which == "adj" and lib.phx_debug_adjoint_kernel(N, H, B, T, _lib.CTRL_PER_TRAJECTORY) == 2
+kern = lib.phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS[wl["method"]]) if which == "adj" else 0
+second = kern == 2
+if kern == 3:
+    names = ["other (barriers, tails)", "sweeps: P1' only", "sweeps: fused P2'+P1'", "reduce-scatter (+FSAL rows)", "gather hidden rows (1st tile)",
+             "sweeps: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "quadrature + accept", "-",
+             "block: tile wait", "block: consume tiles + requests", "block: P2' + k", "block: input + act + P1'"]
 if second:
     names = ["other (between blocks)", "sweep tail P1-only", "drain+flag+publish", "reduce owned rows", "gather hidden rows", "sweep tail fused", "init(weights,y0)", "-", "norms (gather+pair sync)", "controller", "accept pass", "quadrature", "block: tile wait", "block: finish (VALU)", "block: requests+P1+P2 MFMA", "-"]
 clk = None
