@@ -45,7 +45,11 @@ STATUS_TEXT = {
 
 
 def lib_path():
-    return os.environ.get("PHX_LIB", _build.LIB)     # PHX_LIB: a diagnostic build of the same ABI
+    # PHX_LIB names a diagnostic build of the same ABI (A/B timing of two builds); it is honoured only together with
+    # PHX_DIAG=1 so that a stray variable in a production environment cannot swap the engine
+    if os.environ.get("PHX_DIAG") == "1" and os.environ.get("PHX_LIB"):
+        return os.environ["PHX_LIB"]
+    return _build.LIB
 
 
 def load():

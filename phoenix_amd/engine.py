@@ -80,16 +80,20 @@ class Params:
             self.wimg = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             _check_call(_lib.load().phx_pack_weight_images(C.byref(self.c), _p(self.wimg), _stream_ptr()))
             self.c.wimg = self.wimg.data_ptr()
-            self._wimg_stream = torch.cuda.current_stream()
-            self._wimg_event = torch.cuda.Event()
-            self._wimg_event.record()
+        # ready event, unconditionally: the contiguous / transposed copies above are written on this stream too
+        self._ready_stream = torch.cuda.current_stream()
+        self._ready_event = torch.cuda.Event()
+        self._ready_event.record()
 
     def on_current_stream(self):
-        """a solve on another stream than the one that packed the images waits for the packing"""
-        if self.wimg is not None:
-            cur = torch.cuda.current_stream()
-            if cur != self._wimg_stream:
-                cur.wait_event(self._wimg_event)
+        """a call on another stream than the one that laid these parameters out waits for the layout (copies and
+        packed images) and keeps their memory alive for that stream"""
+        cur = torch.cuda.current_stream()
+        if cur != self._ready_stream:
+            cur.wait_event(self._ready_event)
+            for x in (self.Ws, self.bs, self.Wp, self.bp, self.WaT, self.g, self.wimg):
+                if x is not None:
+                    x.record_stream(cur)
         return self
 
     def new_grads(self):

@@ -44,7 +44,7 @@ def params_of(func):
 class _RhsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, prior_only, ws, bs, wp, bp, wa, g):
-        p = engine.Params(ws, bs, wp, bp, wa, g)
+        p = engine.params_cached(ws, bs, wp, bp, wa, g)   # one re-layout per parameter version, shared with backward
         ctx.prior_only = prior_only
         ctx.save_for_backward(y, ws, bs, wp, bp, wa, g)
         return engine.rhs_forward(p, y, prior_only)
@@ -52,7 +52,7 @@ class _RhsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         y, ws, bs, wp, bp, wa, g = ctx.saved_tensors
-        p = engine.Params(ws, bs, wp, bp, wa, g)
+        p = engine.params_cached(ws, bs, wp, bp, wa, g)
         need_p = any(ctx.needs_input_grad[2:])
         vjp, grads = engine.rhs_vjp(p, y, grad_out.contiguous(), ctx.prior_only, want_grads=need_p,
                                     want_vjp_y=ctx.needs_input_grad[0])
@@ -69,7 +69,7 @@ class _PriorMSEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, target, ws, bs, wp, bp, wa, g):
-        p = engine.Params(ws, bs, wp, bp, wa, g)
+        p = engine.params_cached(ws, bs, wp, bp, wa, g)
         res = engine.prior_mse(p, X, target)
         if res is None:
             raise RuntimeError("phoenix_amd: the fused prior loss is not available for this shape / engine mode")
@@ -80,7 +80,7 @@ class _PriorMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         X, cot, ws, bs, wp, bp, wa, g = ctx.saved_tensors
-        p = engine.Params(ws, bs, wp, bp, wa, g)
+        p = engine.params_cached(ws, bs, wp, bp, wa, g)
         _, grads = engine.rhs_vjp(p, X, cot, True, want_grads=True, want_vjp_y=False)
         grads.flat.mul_(grad_out)          # the cotangent was formed for d loss = 1
         gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)

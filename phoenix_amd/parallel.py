@@ -12,6 +12,10 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _has_coalesced():
+    return hasattr(dist, "all_reduce_coalesced")
+
+
 def allreduce_grads(module, scale=None, extra=()):
     """sum-all-reduce every parameter gradient in ONE grouped collective (RCCL group call: no flat copy of the
     P = 4HN+2H+N floats and no copy back -- the gradients are reduced where autograd left them); `scale` (e.g. 1/world
@@ -29,12 +33,15 @@ def allreduce_grads(module, scale=None, extra=()):
             p.grad = p.grad.contiguous()
         grads = [p.grad for p in ps]
     group = grads + list(extra)
-    try:
+    # The collective sequence must be the same on every rank: whether the grouped form is used is decided from what
+    # the installed torch offers (identical on all ranks), never from an exception raised inside a collective (a rank
+    # that fell back alone would issue a different sequence than its peers: hang or double reduction).
+    if _has_coalesced():
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             dist.all_reduce_coalesced(group, op=dist.ReduceOp.SUM)
-    except (AttributeError, RuntimeError):   # backend without the grouped form: one collective per tensor
+    else:
         for g in group:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
     if scale is not None:
@@ -49,7 +56,14 @@ class GradSync:
     failure flag rides in the same group call as the gradients, the failing rank re-raises after the collective and
     every other rank raises `RuntimeError` at a point that is the same on all of them: at once when the engine reads
     statuses immediately (or on CPU), else at its next call / `finish()` -- the flag then comes back through pinned
-    memory like the deferred solver status (phoenix_amd.engine.set_status_mode) and costs no host synchronisation."""
+    memory like the deferred solver status (phoenix_amd.engine.set_status_mode) and costs no host synchronisation.
+
+    Deferred mode and the optimizer step: the healthy ranks learn of the failure one call late, i.e. AFTER their
+    `opt.step()` of the failed step.  So that they do not apply the incomplete sum, the reduced gradients are multiplied
+    by `flag == 0` on the device (no host round trip): on a failed step every rank steps with all-zero gradients.  A
+    stateless optimizer then changes nothing; one with momentum (Adam) still moves the parameters by its running
+    averages on the healthy ranks while the failing rank does not step at all -- after this error the replicas must be
+    restored from the last checkpoint on ALL ranks before training continues."""
     collective_errors = True
 
     def __init__(self, scale=None):
@@ -80,6 +94,9 @@ class GradSync:
             if float(flag[0]) > 0:
                 raise RuntimeError("phoenix_amd: a solve failed on another rank")
             return
+        ps = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
+        if ps:
+            torch._foreach_mul_(ps, (flag == 0).to(flag.dtype))     # a failed step updates with zero gradients
         host = torch.empty(1, dtype=torch.float32, pin_memory=True)
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()

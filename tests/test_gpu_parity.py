@@ -14,7 +14,9 @@ KEYS = ("Ws", "bs", "Wp", "bp", "Wa", "g")
 TOL_RHS = 5e-6        # fp32 sums in a different order (tree/shuffle vs MKL)
 TOL_FIXED = 1e-5      # north_star tolerance on trajectories
 TOL_DOPRI = 1e-5
-TOL_DOPRI_GRAD = 3e-5  # see tests/test_oracle_vs_golden.py: adaptive fp32 noise floor of the gradients
+TOL_DOPRI_GRAD = 2.5e-5  # see tests/test_oracle_vs_golden.py: adaptive fp32 noise floor of the gradients (round 2: 3e-5;
+                         # 2e-5 is crossed by the VALU engine and the MFMA engines alike on one multi-step case: 2.2e-5)
+TOL_DOPRI_GRAD_1STEP = 1e-5   # intervals one accepted step long (the breast-cancer pseudotime grid): no accept/reject noise
 
 
 @pytest.fixture(scope="module")
@@ -144,7 +146,8 @@ def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(pa, dev):
     """The engine's dopri5 gradients against the fp64 tight-tolerance truth of the six G4 problems, held to the
     reference's OWN measured distance from that truth (golden G12: its fp32 gradients at rtol * {0.85 ... 1.15};
     rtol = 1e-7 is below fp32 epsilon, so this distance -- median 7.7e-6, max 1.3e-5 -- is the noise floor of the
-    algorithm, not of an implementation): median within 1.5 x the reference's median (six cases against forty-two reference runs), worst case within 2 x its worst."""
+    algorithm, not of an implementation): median within 1.25 x the reference's median (six cases against forty-two
+    reference runs), worst case within 1.5 x its worst (round 2: 1.5 x / 2 x)."""
     g, sp = load_golden("g4_dopri5"), load_golden("g12_spread")
     net = make_net(pa, dev, sub(g, "p_"))
     ref_err, our_err = [], []
@@ -162,8 +165,8 @@ def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(pa, dev):
                                [relerr(got[k], s["truth64/grad_" + k]) for k in KEYS]))
     print("gradient error vs fp64 truth: engine median %.2e max %.2e | reference median %.2e max %.2e" %
           (np.median(our_err), max(our_err), np.median(ref_err), max(ref_err)))
-    assert np.median(our_err) <= 1.5 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
-    assert max(our_err) <= 2.0 * max(ref_err), (max(our_err), max(ref_err))
+    assert np.median(our_err) <= 1.25 * np.median(ref_err), (np.median(our_err), np.median(ref_err))
+    assert max(our_err) <= 1.5 * max(ref_err), (max(our_err), max(ref_err))
 
 
 def test_g4_per_sample_loop_as_one_launch(pa, dev):
@@ -339,13 +342,15 @@ def test_rhs_vjp_kernel_chain_vs_oracle_rows_and_valu_engine(pa, dev, oracle, mo
 
 
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
-@pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1100, 16, 5)])
+@pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1100, 16, 5),
+                                   (350, 40, 150), (1100, 16, 37)])   # the last two: batches that do not fill their last group
 def test_per_sample_solve_and_adjoint_vs_oracle(pa, dev, oracle, method, N, H, B):
     p = rand_params(N, H, seed=7 * N + H, std=0.05)
     net, onet = make_net(pa, dev, p), onet_of(oracle, p)
     r = np.random.RandomState(2)
     y0 = r.rand(B, N).astype(np.float32)
-    t = np.stack([np.array([0.1 * b, 0.1 * b + 0.4 + 0.05 * b]) for b in range(B)]).astype(np.float32)
+    # interval lengths 0.4 .. 3.55 (longer ones make the single-step rk4 solve ill-conditioned in fp32)
+    t = np.stack([np.array([0.1 * b, 0.1 * b + 0.4 + 0.05 * (b % 64)]) for b in range(B)]).astype(np.float32)
     G = r.randn(B, 2, N).astype(np.float32)
     ref = oracle.odeint_per_sample(onet, y0, t, method=method)                       # [B,2,N]
     adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=False)
@@ -482,6 +487,72 @@ def test_full_size_breast_properties(pa, dev, oracle):
         assert relerr(acc[k], full[k]) < 2e-5, k
 
 
+@pytest.mark.parametrize("B", [256, 200])
+def test_full_size_breast_every_row_vs_oracle(pa, dev, oracle, B):
+    """BASELINE config C4 at full size (N=11165, H=40, dopri5 + adjoint, the pseudotime interval of the bench): EVERY
+    row of the batch -- trajectories, dL/dy0 -- and the parameter gradient of the whole batch against the oracle running
+    the reference's per-sample loop WITH the parameter block in the adjoint's step-control norm (adjoint.py:72-78,
+    `theta_in_norm=True`): cotangents at the scale `torch.mean((pred - target)**2)` produces, where the engine's
+    deviation (no parameter block on the device) must be inert.  B = 256 is the configuration; B = 200 leaves the last
+    batch group with one ragged tile and three padding-only ones."""
+    N, H = 11165, 40
+    p = rand_params(N, H, seed=11, std=0.02)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(4 + B)
+    y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
+    t = np.tile(np.array([[0.0, 0.0051]], np.float32), (B, 1))
+    G = (r.randn(B, 2, N) * (2.0 / (B * N))).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+    got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+    worst_row = np.abs(got - ref).reshape(B, -1).max(1) / np.abs(ref).max()
+    assert worst_row.max() < TOL_DOPRI, int(worst_row.argmax())
+    (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+    ga = y0t.grad.cpu().numpy().reshape(B, N)
+    worst_row = np.abs(ga - adj_ref).max(1) / np.abs(adj_ref).max()
+    assert worst_row.max() < TOL_DOPRI_GRAD_1STEP, int(worst_row.argmax())
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD_1STEP, k
+
+
+def test_full_size_bcell_rows_of_every_group_vs_oracle(pa, dev, oracle):
+    """BASELINE config C5 at full size (N=14691, H=200 -> two hidden chunks, B=256, dopri5 + adjoint over [0, 1]): 32 rows
+    that cover every batch group and the first and last trajectory tile of each, against the oracle with the parameter
+    block in the norm (training-scale cotangents).  The engine runs the whole 256-row batch; its rows are compared one by
+    one, and its parameter gradient on exactly those rows (a second launch of the 32 rows) with the oracle's."""
+    N, H, B = 14691, 200, 256
+    p = rand_params(N, H, seed=21, std=0.004)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(19)
+    y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
+    t = np.tile(np.array([[0.0, 1.0]], np.float32), (B, 1))
+    G = (r.randn(B, 2, N) * (2.0 / (B * N))).astype(np.float32)
+    rows = sorted(set(list(range(0, 4)) + list(range(60, 68)) + list(range(124, 132)) + list(range(188, 196)) +
+                      list(range(252, 256))))
+    assert len(rows) == 32
+    ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[rows], method="dopri5", theta_in_norm=True)
+    y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+    tt = torch.from_numpy(t).to(dev)
+    Gt = torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)
+    sol = pa.odeint_adjoint(net, y0t, tt)
+    (sol * Gt).sum().backward()
+    got = sol.detach()[:, rows, 0].cpu().numpy().transpose(1, 0, 2)
+    assert relerr(got, ref) < TOL_DOPRI
+    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    zero_grads(net)
+    yr = y0t.detach()[rows].clone().requires_grad_(True)
+    sr = pa.odeint_adjoint(net, yr, tt[rows])
+    (sr * Gt[:, rows]).sum().backward()
+    assert relerr(yr.grad[:, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    gg = grads_of(net)
+    for k in KEYS:
+        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+
+
 def test_full_size_insilico_vs_oracle(pa, dev, oracle):
     """BASELINE config C2 at full size (N=350, H=40, 1024 trajectories x 4 intervals, fused 3/8-rule rk4 + adjoint):
     every row against the oracle (per-sample semantics), gradients summed over the batch."""
@@ -518,7 +589,8 @@ def test_full_size_yeast_vs_oracle(pa, dev, oracle):
     t = np.tile(np.array([[0.0, 5.0]], np.float32), (B, 1))
     G = (r.randn(B, 2, N) / (B * N)).astype(np.float32)
     ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
-    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+    # training-scale cotangents: the oracle keeps the reference's parameter block in the adjoint norm (adjoint.py:72-78)
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
     y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
     got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
@@ -602,7 +674,7 @@ def test_forward_failure_raises_under_no_grad(pa, dev):
         pa.odeint_adjoint(net, y0, t, method="dopri5", options={"max_num_steps": 2})
 
 
-@pytest.mark.parametrize("variant", ["default", "v0", "adj1", "adj2_np2", "adj2_np4"])
+@pytest.mark.parametrize("variant", ["default", "v0", "adj1", "adj2_np2", "adj2_np4", "adj3"])
 def test_max_num_steps_is_a_budget_per_output_time(pa, dev, monkeypatch, variant):
     """The reference restarts n_steps in every _advance(next_t) (rk_common.py:152-156) and the adjoint solves interval
     by interval (adjoint.py:136-154): a budget between the largest per-interval count and the total must pass."""
@@ -610,6 +682,8 @@ def test_max_num_steps_is_a_budget_per_output_time(pa, dev, monkeypatch, variant
         monkeypatch.setenv("PHX_ENGINE", "v0")
     elif variant == "adj1":
         monkeypatch.setenv("PHX_ADJ", "v1")
+    elif variant == "adj3":
+        monkeypatch.setenv("PHX_ADJ", "v3")
     elif variant.startswith("adj2"):
         monkeypatch.setenv("PHX_ADJ", "v2")
         monkeypatch.setenv("PHX_ADJ2_NP", variant[-1])
@@ -700,14 +774,16 @@ def test_solve_beside_a_busy_second_stream(pa, dev):
 
 
 # --------------------------------------------------------------------------- engine variants
-@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4"])
+@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4", "adj3"])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
 def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant, method):
     """The v0 (VALU, grid-barrier) kernels remain the fallback for shapes the v1 (MFMA) plan rejects, v1 has several
-    workgroup geometries, and the backward solve has two generations of kernels (the second in a four- and an
-    eight-wave form) chosen by shape: every variant must pass the same oracle check."""
+    workgroup geometries, and the backward solve has three kernels (the second in a four- and an eight-wave form, the
+    third for dopri5 with a narrow hidden layer) chosen by shape: every variant must pass the same oracle check."""
     if variant == "v0":
         monkeypatch.setenv("PHX_ENGINE", "v0")
+    elif variant == "adj3":
+        monkeypatch.setenv("PHX_ADJ", "v3")       # dopri5 only: rk4 falls through to the shape's usual kernel
     elif variant == "adj1":
         monkeypatch.setenv("PHX_ADJ", "v1")
     elif variant.startswith("adj2"):
@@ -1056,7 +1132,8 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
     G = r.randn(T, B, 1, N).astype(np.float32)
     res = {}
     # "alt": the backward-kernel generation / geometry the planner would NOT pick for this shape
-    alt = [{"PHX_ADJ": "v2", "PHX_ADJ2_NP": "2"}, {"PHX_ADJ": "v2", "PHX_ADJ2_NP": "4"}, {"PHX_ADJ": "v1"}][seed % 3]
+    alt = [{"PHX_ADJ": "v2", "PHX_ADJ2_NP": "2"}, {"PHX_ADJ": "v2", "PHX_ADJ2_NP": "4"}, {"PHX_ADJ": "v1"},
+           {"PHX_ADJ": "v3"}][seed % 4]
     for eng in ("v1", "v0", "alt"):
         if eng == "v0":
             os.environ["PHX_ENGINE"] = "v0"
@@ -1164,7 +1241,7 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
         return [x.clone() for x in out]
 
     results = {}
-    for variant, env in (("default", {}), ("first kernel", {"PHX_ADJ": "v1"})):
+    for variant, env in (("default", {}), ("first kernel", {"PHX_ADJ": "v1"}), ("third kernel", {"PHX_ADJ": "v3"})):
         for k in ("PHX_ADJ", "PHX_ADJ2_NP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -1177,8 +1254,9 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
         for a, b in zip(clean, dirty):
             assert torch.equal(a, b), variant
         results[variant] = clean
-    for a, b in zip(results["default"][1:3], results["first kernel"][1:3]):      # adj_y0 and the six gradients
-        assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+    for other in ("default", "third kernel"):
+        for a, b in zip(results[other][1:3], results["first kernel"][1:3]):      # adj_y0 and the six gradients
+            assert relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, other
 
 
 def test_other_stream_and_mixed_time_directions(pa, dev, oracle):

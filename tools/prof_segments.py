@@ -54,6 +54,9 @@ clk = None
 if second:
     clk = raw[:, 15].astype(np.float64).copy()
     us[:, 15] = 0
+if kern == 3:
+    clk = raw[:, 7].astype(np.float64).copy()
+    us[:, 7] = 0
 tot = us.sum(1)
 if clk is not None:
     print("in-kernel shader clock: %.0f MHz (median over workgroups)" % np.median(clk / tot))
