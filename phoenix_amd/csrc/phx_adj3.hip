@@ -99,8 +99,8 @@ Layout3 make_layout3(const D1 &d, bool grads)
     L.dtheta = take(grads ? PP * 4 * d.TG * d.NW : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
-    // wave-private transposed hidden rows of the seven ring slots: [workgroup][tile][7][4 HT][64 lanes] float4
-    L.hq = take(grads ? (size_t)d.TG * d.G * d.ntg * 7 * 4 * d.HT * 1024 : 0);
+    // transposed hidden rows of the seven ring slots, shared by a group's workgroups: [group][tile][7][4 HT][64] float4
+    L.hq = take(grads ? (size_t)d.TG * d.ntg * 7 * 4 * d.HT * 1024 : 0);
     L.total = off;
     return L;
 }
@@ -165,8 +165,10 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         w1.zbuf = (unsigned long long *)(base + L.zbuf);
         w1.scratch = (float *)(base + L.scratch);
         w1.dtheta = (float *)(base + L.dtheta);
-        const char *pe = getenv("PHX_PROF");
-        w1.prof = (pe && pe[0] == '1') ? (unsigned long long *)(base + L.prof) : nullptr;
+        const char *pe = getenv("PHX_PROF");   // 1: segment timers, 2: + per-block timers of the sweeps, 3: + of the quadrature
+        const int plevel = pe ? atoi(pe) : 0;
+        w1.prof = plevel >= 1 ? (unsigned long long *)(base + L.prof) : nullptr;
+        const int prof_flags = (plevel == 2 ? 2 : 0) | (plevel == 3 ? 4 : 0);
         w1.wimg = (const float *)(base + L.wimg);
         w1.hq = (float *)(base + L.hq);
         const size_t lds = lds_bytes_adj3(d1);
@@ -189,7 +191,7 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
         ev_begin(st);
         hipLaunchKernelGGL((k1_solve_adj3<3>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y, adj_y0,
-                           status, nfe, nsteps, grads ? 1 : 0, PP);
+                           status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PHX_PROF"] = "1"
+os.environ.setdefault("PHX_PROF", "1")
 import bench  # noqa: E402
 from phoenix_amd import _lib, engine  # noqa: E402
 
@@ -48,6 +48,8 @@ if kern == 3:
     names = ["other (barriers, tails)", "sweeps: P1' only", "sweeps: fused P2'+P1'", "reduce-scatter (+FSAL rows)", "gather hidden rows (1st tile)",
              "sweeps: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "quadrature + accept", "-",
              "block: tile wait", "block: consume tiles + requests", "block: P2' + k", "block: input + act + P1'"]
+    if os.environ["PHX_PROF"] == "3":
+        names[10:15] = ["quad: other (loop, hq of stage 0)", "quad: tile wait", "quad: seven stages", "quad: partial stores", "quad: accept pass"]
 if second:
     names = ["other (between blocks)", "sweep tail P1-only", "drain+flag+publish", "reduce owned rows", "gather hidden rows", "sweep tail fused", "init(weights,y0)", "-", "norms (gather+pair sync)", "controller", "accept pass", "quadrature", "block: tile wait", "block: finish (VALU)", "block: requests+P1+P2 MFMA", "-"]
 clk = None
