@@ -80,6 +80,9 @@ int pick_chunk_adj3(int N, int H, int B, int T, int control, int method)
     return 0;
 }
 
+// floats of one wave's partial: accumulator-native [gene block][4 HT x 2][64] float4, then dg [N], dbs [H], dbp [H]
+size_t pp_adj3(const D1 &d) { return align_up((size_t)d.nblk * (4 * d.HT * 2 * 256) + d.N + 2 * d.H, 64); }
+
 struct Layout3 {
     size_t total, cnt, part, zbuf, scratch, dtheta, prof, xbytes, wimg, hq;
 };
@@ -95,8 +98,7 @@ Layout3 make_layout3(const D1 &d, bool grads)
     L.zbuf = take((size_t)d.TG * R * 64 * 8);
     L.xbytes = off - L.part;                                 // granule buffers are zeroed before every launch
     L.scratch = take((size_t)d.TG * d.G * NVEC_ADJ3 * d.ntg * d.NB * 512 * 4);
-    const size_t PP = align_up((size_t)4 * d.H * d.N + d.N + 2 * d.H, 4);
-    L.dtheta = take(grads ? PP * 4 * d.TG * d.NW : 0);
+    L.dtheta = take(grads ? pp_adj3(d) * 4 * d.TG * d.NW : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
     // transposed hidden rows of the seven ring slots, shared by a group's workgroups: [group][tile][7][4 HT][64] float4
@@ -172,7 +174,7 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         w1.wimg = (const float *)(base + L.wimg);
         w1.hq = (float *)(base + L.hq);
         const size_t lds = lds_bytes_adj3(d1);
-        const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
+        const long long PP = (long long)pp_adj3(d1);
         const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW;   // waves that own tiles
         // counters + granule buffers are contiguous: one fill
         if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
@@ -195,10 +197,9 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {
-            const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-            const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-            hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, npart, PP, p->N, p->H,
-                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
+            const long long total = (long long)d1.nblk * (4 * d1.HT * 2 * 64) + p->N + 2 * p->H;
+            hipLaunchKernelGGL((k3_reduce_grads<3>), dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, w1.dtheta, npart, PP,
+                               p->N, p->H, d1.nblk, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
                                (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         }

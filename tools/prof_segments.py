@@ -49,7 +49,7 @@ if kern == 3:
              "sweeps: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "quadrature + accept", "-",
              "block: tile wait", "block: consume tiles + requests", "block: P2' + k", "block: input + act + P1'"]
     if os.environ["PHX_PROF"] == "3":
-        names[10:15] = ["quad: other (loop, hq of stage 0)", "quad: tile wait", "quad: seven stages", "quad: partial stores", "quad: accept pass"]
+        names[10:16] = ["quad: other (loop, requests)", "quad: tile wait", "quad: seven stages", "quad: partial stores", "quad: accept pass", "quad: acquire"]
 if second:
     names = ["other (between blocks)", "sweep tail P1-only", "drain+flag+publish", "reduce owned rows", "gather hidden rows", "sweep tail fused", "init(weights,y0)", "-", "norms (gather+pair sync)", "controller", "accept pass", "quadrature", "block: tile wait", "block: finish (VALU)", "block: requests+P1+P2 MFMA", "-"]
 clk = None
