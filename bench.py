@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="breast", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="profiling runs: only the timed loop and the per-kernel timing (no training step, no "
+                         "strong-scaling shards: their launches would be averaged into the per-kernel profile)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--status", default="deferred", choices=["deferred", "immediate"],
                     help="solver status read-back: behind the backward kernel (checked at a later engine call) or a "
@@ -398,7 +401,7 @@ def main():
                       "augmented_evals_per_s": nfe_aug * N / (adj_ms_avg * 1e-3),
                       "kernel_ms_per_step": fwd_ms_avg + adj_ms_avg},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # informational: the reference's full training_step (train_insilico.py:124-140) with its K = 10 000-row
             # prior branch and an Adam step; NOT part of `value` (the metric counts ODE RHS evaluations only)
             try:
