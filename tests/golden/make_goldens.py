@@ -19,6 +19,7 @@ Goldens:
   G10 analysis      gene-influence scoring loop (find_gene_influences.py:64-77) and calculate_trajectory (datahandler.py:310-340)
   G12 spread        the reference's OWN dopri5 gradients at rtol * {0.85 ... 1.15} and an fp64 tight-tolerance truth (G4 inputs)
   G11 hill          rate expressions of the 350-gene ground-truth network: rates and LSODA trajectories (GraphGRN_core.R:425-486)
+  G13 hill690       the same for the 690-gene network (ode_system_functions_690.csv)
   G8 prior          read_prior_matrix (dense + triplet formats) and prior_grad = X @ P   (train_insilico.py:64-73,207-211)
 """
 import ast
@@ -554,6 +555,23 @@ def g11_hill():
     save("g11_hill", names=np.array(names), eqns=np.array(exprs), X=X, rates=rates, times=times, x0=x0, traj=traj)
 
 
+def g13_hill690():
+    """G11 for the second shipped network: ground_truth_simulator/clean_data/ode_system_functions_690.csv (690 nodes).
+    Same recipe -- expression strings as input arrays, Python fp64 rates on random states, scipy LSODA trajectories."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import hill_oracle
+    from phoenix_amd.simulator import read_ode_system
+    names, exprs = read_ode_system("/root/reference/ground_truth_simulator/clean_data/ode_system_functions_690.csv")
+    rs = np.random.RandomState(13)
+    X = rs.rand(8, len(names))
+    X[0, :5] = 0.0
+    rates = hill_oracle.rhs(names, exprs, X)
+    times = np.array([0.0, 2.0, 3.0, 7.0, 9.0])
+    x0 = np.clip(rs.beta(2, 2, size=(2, len(names))) + rs.uniform(-0.25, 0.25, size=(1, len(names))), 0, 1)
+    traj = np.stack([hill_oracle.simulate(names, exprs, x0[i], times) for i in range(2)], 1)   # [T, 2, N]
+    save("g13_hill690", names=np.array(names), eqns=np.array(exprs), X=X, rates=rates, times=times, x0=x0, traj=traj)
+
+
 # ---------------------------------------------------------------- G12 (spread of the reference's own gradients)
 def g12_spread():
     """rtol = 1e-7 is below fp32 epsilon: accept/reject decisions of the adaptive solver are rounding noise, so the
@@ -591,7 +609,8 @@ def g12_spread():
 
 if __name__ == "__main__":
     for only, fn in (("--only-g8", "g8_prior"), ("--only-g9", "g9_datahandler"), ("--only-g10", "g10_analysis"),
-                     ("--only-g11", "g11_hill"), ("--only-g12", "g12_spread")):
+                     ("--only-g11", "g11_hill"), ("--only-g12", "g12_spread"),
+                     ("--only-g13", "g13_hill690")):
         if only in sys.argv:
             globals()[fn]()
             sys.exit(0)
@@ -605,4 +624,5 @@ if __name__ == "__main__":
     g9_datahandler()
     g10_analysis()
     g11_hill()
+    g13_hill690()
     g12_spread()

@@ -25,10 +25,16 @@ def _system(g, device, tmp_path=None):
     return HillSystem.from_csv(path, device=device)
 
 
-def test_compiled_programs_match_the_expression_strings(tmp_path):
-    g = load_golden("g11_hill")
+@pytest.mark.parametrize("fixture,N,n_input", [("g11_hill", 350, 74), ("g13_hill690", 690, None)])
+def test_compiled_programs_match_the_expression_strings(tmp_path, fixture, N, n_input):
+    """both shipped networks (ode_system_functions_350.csv / _690.csv): 74 "input gene" rows in the 350-gene one"""
+    g = load_golden(fixture)
     sys_ = _system(g, "cpu", tmp_path)
-    assert sys_.N == 350 and int(sys_.is_input.sum()) == 74          # 74 "input gene" rows in the shipped network
+    assert sys_.N == N
+    if n_input is None:
+        n_input = sum(1 for e in g["eqns"] if "input gene" in str(e))
+        assert n_input > 0
+    assert int(sys_.is_input.sum()) == n_input
     from oracle import hill_oracle
     got = hill_oracle.interpret_programs(sys_.code_host, sys_.consts_host, sys_.off_host, sys_.len_host, g["X"])
     assert np.max(np.abs(got - g["rates"])) < 1e-12
@@ -51,6 +57,21 @@ def test_unsupported_syntax_is_rejected():
         HillSystem(["A", "B"], ["A ** 2", "input gene"], device="cpu")
     with pytest.raises(ValueError):
         HillSystem(["A", "B"], ["fAct(C, 0.5, 1.2) - A", "input gene"], device="cpu")
+
+
+@pytest.mark.gpu
+def test_hill_690_gene_network_on_device():
+    """the second shipped expression file (690 nodes): phx_hill_rhs / phx_hill_simulate against golden G13"""
+    g = load_golden("g13_hill690")
+    dev = torch.device("cuda:0")
+    sys_ = _system(g, dev)
+    assert sys_.N == 690
+    rates = sys_.rhs(torch.from_numpy(g["X"]).float().to(dev)).cpu().numpy()
+    assert np.max(np.abs(rates - g["rates"])) < 5e-6
+    traj = sys_.simulate(torch.from_numpy(g["x0"]).float().to(dev), g["times"]).cpu().numpy()
+    assert traj.shape == g["traj"].shape
+    assert np.max(np.abs(traj - g["traj"])) / np.max(np.abs(g["traj"])) < 1e-5
+    assert np.array_equal(traj[-1][:, sys_.is_input], traj[0][:, sys_.is_input])
 
 
 @pytest.mark.gpu
