@@ -13,6 +13,7 @@
 using namespace phxh;
 
 #include "phx_mfma_common.inc"
+#include "phx_mfma_v3common.inc"
 #include "phx_mfma_adj3.inc"
 
 namespace {

@@ -1253,6 +1253,7 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     D1 d1;
     if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
     const bool adj = op == PHX_OP_ADJOINT;
+    if (!adj && fwd3_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (adj && adj3_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (adj && adj2_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1, adj ? 40 : 0,
@@ -1283,6 +1284,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     const Dims d = make_dims(N, H, B, T, PHX_CTRL_PER_TRAJECTORY);
     size_t need = make_layout(d, op).total;
     if (op == PHX_OP_ODEINT) {
+        need = std::max(need, fwd3_workspace_bytes(N, H, B, T));
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl) {
             const int bc = pick_chunk_v1(N, H, B, T, ctl, false);
@@ -1493,6 +1495,9 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
         if (o->control != PHX_CTRL_SHARED || B % calls != 0) return PHX_ERR_BAD_ARG;
         Bcall = B / calls;
     }
+    // third-generation forward kernel (dopri5, narrow hidden layer; phx_fwd3.hip)
+    if (!Bcall && fwd3_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
+        return fwd3_run(p, y0_all, t_all, B, T, o, sol_all, status_all, nfe_all, nsteps_all, workspace, workspace_bytes, st);
     // v1: MFMA kernels with LDS-resident weights, when the shape fits (large batches: in chunks)
     const int chunk_f = Bcall ? pick_calls_v1(p->N, p->H, B, T, calls) * Bcall : pick_chunk_v1(p->N, p->H, B, T, o->control, false);
     if (Bcall && chunk_f == 0) return PHX_ERR_BAD_ARG;

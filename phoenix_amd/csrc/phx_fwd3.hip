@@ -1,0 +1,191 @@
+// phx_fwd3.hip -- translation unit of the third-generation forward solve (k1_solve_fwd3, phx_mfma_fwd3.inc): launch
+// planning, workspace layout and the host entry points the C ABI (phx_engine.hip) calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "phx_solver.hpp"
+#include "phx_host.hpp"
+
+using namespace phxh;
+
+#include "phx_mfma_common.inc"
+#include "phx_mfma_v3common.inc"
+#include "phx_mfma_fwd3.inc"
+
+namespace {
+
+bool fwd3_disabled()
+{
+    const char *e = getenv("PHX_FWD");   // diagnostic: PHX_FWD=v1 keeps every forward solve on k1_solve_fwd
+    return force_v0() || (e && strcmp(e, "v1") == 0);
+}
+
+// (NW, TPW, NB) as plan_v1 picks them for the forward kernel: per-SIMD MFMA work first, then two waves per SIMD, then
+// the smallest batch group
+bool plan_fwd3(int N, int H, int B, int T, int control, int method, D1 *out)
+{
+    const int cus = num_cus();
+    if (cus <= 0 || fwd3_disabled() || method != PHX_DOPRI5 || H > 48) return false;
+    const int HT = 3;
+    const size_t blkbytes = (size_t)blk_floats_ch(HT, H) * 4;
+    const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
+    long long best_cost = -1;
+    D1 best{};
+    // One wave per SIMD (NW <= 4).  The eight-wave form (two waves per SIMD under a 256-register cap) needs scratch
+    // spills, and with them trajectories 12..15 of the tiles of waves 4..7 came out with wrong error norms as soon as a
+    // launch had more than 1024 waves (TG x G > 128 workgroups; measured with tools/fwd3_check.py) -- not understood,
+    // so that form is not built.  Four waves are faster than k1_solve_fwd's eight at C4 anyway (0.27 vs 0.29 ms).
+    int nwmax = 4;
+    if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
+    for (int NW = nwmax; NW >= 1; NW >>= 1)
+        for (int TPW = 1; TPW <= 4; TPW <<= 1) {
+            const int slots = NW * TPW, TG = (ntt + slots - 1) / slots;
+            const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
+            const bool helpers = ntg < slots;
+            if (control == PHX_CTRL_SHARED && TG != 1) continue;
+            const size_t cb = ctlf3_bytes(Bt, ntg);
+            if (cb + blkbytes > LDS_BUDGET) continue;
+            const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
+            for (int NB = 1; NB <= NBmax; ++NB) {
+                const int G = (nblk + NB - 1) / NB;
+                if ((long long)TG * G > cus) continue;
+                const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (4 - NW) * 100 + Bt / 4 -
+                                       (helpers && TPW == 1 ? 50 : 0);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    best.N = N; best.H = H; best.B = B; best.T = T; best.HT = HT; best.NB = NB; best.NW = NW;
+                    best.TPW = TPW; best.G = G; best.TG = TG; best.nblk = nblk; best.ntg = ntg; best.Bt = Bt;
+                    best.nvec = NVEC_FWD3; best.BN = (long long)B * N; best.HC = 1; best.Hc = H;
+                    best.Bcall = 0; best.cntN = (long long)B * N;
+                }
+                break;  // smallest feasible NB for this (NW, TPW) is the cheapest
+            }
+        }
+    if (best_cost < 0) return false;
+    *out = best;
+    return true;
+}
+
+int pick_chunk_fwd3(int N, int H, int B, int T, int control, int method)
+{
+    D1 d1;
+    if (plan_fwd3(N, H, B, T, control, method, &d1)) return B;
+    if (control != PHX_CTRL_PER_TRAJECTORY) return 0;
+    for (int bc = 4096; bc >= 16; bc >>= 1)
+        if (bc < B && plan_fwd3(N, H, bc, T, control, method, &d1)) return bc;
+    return 0;
+}
+
+struct LayoutF3 {
+    size_t total, cnt, part, zbuf, scratch, prof, xbytes, wimg;
+};
+
+LayoutF3 make_layout_f3(const D1 &d)
+{
+    LayoutF3 L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t R = (size_t)d.ntg * 2 * d.HT * 4 + d.ntg;   // hidden rows + norm rows per group
+    L.cnt = take(4096);
+    L.part = take((size_t)d.TG * d.G * R * 64 * 8);
+    L.zbuf = take((size_t)d.TG * R * 64 * 8);
+    L.xbytes = off - L.part;                                 // granule buffers are zeroed before every launch
+    L.scratch = take((size_t)d.TG * d.G * NVEC_FWD3 * d.ntg * d.NB * 512 * 4);
+    L.prof = take((size_t)d.TG * d.G * 16 * 8);
+    L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
+    L.total = off;
+    return L;
+}
+
+size_t lds_bytes_fwd3(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ctlf3_bytes(d.Bt, d.ntg); }
+
+}  // namespace
+
+namespace phxh {
+
+int fwd3_chunk(int N, int H, int B, int T, int control, int method) { return pick_chunk_fwd3(N, H, B, T, control, method); }
+
+size_t fwd3_workspace_bytes(int N, int H, int B, int T)
+{
+    size_t need = 0;
+    for (int ctl = 0; ctl < 2; ++ctl) {
+        D1 d1;
+        const int bc = pick_chunk_fwd3(N, H, B, T, ctl, PHX_DOPRI5);
+        if (bc > 0 && plan_fwd3(N, H, bc, T, ctl, PHX_DOPRI5, &d1)) need = std::max(need, make_layout_f3(d1).total);
+    }
+    return need;
+}
+
+int fwd3_profile_region(int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups, int *plan6)
+{
+    D1 d1;
+    if (!plan_fwd3(N, H, B, T, control, PHX_DOPRI5, &d1)) return PHX_ERR_BAD_ARG;
+    *offset = make_layout_f3(d1).prof;
+    *n_workgroups = d1.TG * d1.G;
+    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HT; }
+    return PHX_OK;
+}
+
+int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int B, int T, const phx_solve_opts *o,
+             float *sol_all, int *status_all, int *nfe_all, int *nsteps_all, void *workspace, size_t workspace_bytes,
+             hipStream_t st)
+{
+    SolveCfg cfg;
+    cfg.method = o->method; cfg.control = o->control; cfg.t_per_sample = o->t_per_sample; cfg.t_is_f32 = o->t_is_f32;
+    cfg.rtol = (float)o->rtol; cfg.atol = (float)o->atol;
+    cfg.max_steps = o->max_num_steps > 0 ? o->max_num_steps : 2147483647LL;
+    const int chunk = pick_chunk_fwd3(p->N, p->H, B, T, o->control, o->method);
+    if (chunk <= 0) return PHX_ERR_BAD_ARG;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        D1 d1;
+        const int bc = std::min(chunk, B - b0);
+        if (!plan_fwd3(p->N, p->H, bc, T, o->control, o->method, &d1)) return PHX_ERR_BAD_ARG;
+        d1.BN = (long long)B * p->N;   // time stride of the caller's [T,B,N] arrays
+        const float *y0 = y0_all + (long long)b0 * p->N;
+        const double *t = !o->t_per_sample ? t_all   // rows of b0 onward; the buffer holds floats when t_is_f32 == 2
+                          : reinterpret_cast<const double *>(reinterpret_cast<const char *>(t_all) +
+                                                             (size_t)b0 * T * (o->t_is_f32 == 2 ? 4 : 8));
+        float *sol = sol_all + (long long)b0 * p->N;
+        int *status = status_all + b0, *nfe = nfe_all + b0, *nsteps = nsteps_all + b0;
+        const LayoutF3 L = make_layout_f3(d1);
+        if (workspace_bytes < L.total) return PHX_ERR_WORKSPACE;
+        char *base = (char *)workspace;
+        W1 w1{};
+        w1.cnt = (unsigned long long *)(base + L.cnt);
+        w1.abort_flag = (unsigned int *)(base + L.cnt + 2048);
+        w1.part = (unsigned long long *)(base + L.part);
+        w1.zbuf = (unsigned long long *)(base + L.zbuf);
+        w1.scratch = (float *)(base + L.scratch);
+        const char *pe = getenv("PHX_PROF");
+        w1.prof = (pe && atoi(pe) >= 1) ? (unsigned long long *)(base + L.prof) : nullptr;
+        w1.wimg = (const float *)(base + L.wimg);
+        const size_t lds = lds_bytes_fwd3(d1);
+        // counters + granule buffers are contiguous: one fill
+        if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+        const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
+        if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values
+        else
+            hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT, 1, p->H,
+                               blk_floats_ch(d1.HT, p->H));
+        auto launch = [&](auto kern) -> int {
+            const void *fn = reinterpret_cast<const void *>(kern);
+            if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
+            // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
+            if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
+            ev_begin(st);
+            hipLaunchKernelGGL(kern, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status, nfe, nsteps);
+            ev_end(st);
+            return PHX_OK;
+        };
+        const int lrc = launch(k1_solve_fwd3<3, 256>);
+        if (lrc != PHX_OK) return lrc;
+        if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+    }
+    return PHX_OK;
+}
+
+}  // namespace phxh

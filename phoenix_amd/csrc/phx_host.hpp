@@ -123,3 +123,13 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
              const float *grad_y_all, float *adj_y0_all, const phx_grads *grads, int *status_all, int *nfe_all,
              int *nsteps_all, void *workspace, size_t workspace_bytes, hipStream_t st);
 }  // namespace phxh
+
+// ---- third-generation forward solve (phx_fwd3.hip: dopri5, H <= 48)
+namespace phxh {
+int fwd3_chunk(int N, int H, int B, int T, int control, int method);
+size_t fwd3_workspace_bytes(int N, int H, int B, int T);
+int fwd3_profile_region(int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups, int *plan6);
+int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int B, int T, const phx_solve_opts *o,
+             float *sol_all, int *status_all, int *nfe_all, int *nsteps_all, void *workspace, size_t workspace_bytes,
+             hipStream_t st);
+}  // namespace phxh

@@ -26,7 +26,7 @@ def _stream_ptr():
 
 
 _ws_bytes = {}
-_PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS")
+_PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS", "PHX_FWD")
 
 
 def _workspace(op, N, H, B, T, device, calls=1):

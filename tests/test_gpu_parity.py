@@ -774,7 +774,7 @@ def test_solve_beside_a_busy_second_stream(pa, dev):
 
 
 # --------------------------------------------------------------------------- engine variants
-@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4", "adj3"])
+@pytest.mark.parametrize("variant", ["v0", "v1_nw1", "v1_nw2", "adj1", "adj2_np2", "adj2_np4", "adj3", "fwd1"])
 @pytest.mark.parametrize("method", ["rk4", "dopri5"])
 def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant, method):
     """The v0 (VALU, grid-barrier) kernels remain the fallback for shapes the v1 (MFMA) plan rejects, v1 has several
@@ -784,6 +784,8 @@ def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant
         monkeypatch.setenv("PHX_ENGINE", "v0")
     elif variant == "adj3":
         monkeypatch.setenv("PHX_ADJ", "v3")       # dopri5 only: rk4 falls through to the shape's usual kernel
+    elif variant == "fwd1":
+        monkeypatch.setenv("PHX_FWD", "v1")       # first-generation forward kernel where the third would run
     elif variant == "adj1":
         monkeypatch.setenv("PHX_ADJ", "v1")
     elif variant.startswith("adj2"):
@@ -1064,7 +1066,9 @@ def test_odeint_calls_equals_separate_calls(pa, dev, oracle, N, H, B, K, method)
     for k in range(K):
         one, nfe, nsteps = pa.odeint(net, y0d[k], t, method=method, return_stats=True)
         steps.append(int(nsteps[0]))
-        assert relerr(out[k].cpu().numpy(), one.cpu().numpy()) < 5e-6, k
+        # the batched calls run on k1_solve_fwd, a separate dopri5 call with H <= 48 on k1_solve_fwd3: two adaptive solves
+        # agree to the trajectory tolerance, not bit for bit (fixed grids: the same kernel, summation order only)
+        assert relerr(out[k].cpu().numpy(), one.cpu().numpy()) < (TOL_DOPRI if method == "dopri5" else 5e-6), k
     if method == "dopri5" and N <= 700:
         assert len(set(steps)) > 1       # the controllers really were independent
     k = K - 1
@@ -1132,7 +1136,7 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
     G = r.randn(T, B, 1, N).astype(np.float32)
     res = {}
     # "alt": the backward-kernel generation / geometry the planner would NOT pick for this shape
-    alt = [{"PHX_ADJ": "v2", "PHX_ADJ2_NP": "2"}, {"PHX_ADJ": "v2", "PHX_ADJ2_NP": "4"}, {"PHX_ADJ": "v1"},
+    alt = [{"PHX_ADJ": "v2", "PHX_ADJ2_NP": "2"}, {"PHX_ADJ": "v2", "PHX_ADJ2_NP": "4"}, {"PHX_ADJ": "v1", "PHX_FWD": "v1"},
            {"PHX_ADJ": "v3"}][seed % 4]
     for eng in ("v1", "v0", "alt"):
         if eng == "v0":
@@ -1149,7 +1153,7 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
                 sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
                 (sol * torch.from_numpy(G).to(dev)).sum().backward()
         finally:
-            for k in ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP"):
+            for k in ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_FWD"):
                 os.environ.pop(k, None)
         res[eng] = (sol.detach().cpu().numpy(), y0t.grad.cpu().numpy(), grads_of(net))
     what = (N, H, B, T, method, per_sample)
@@ -1241,8 +1245,8 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
         return [x.clone() for x in out]
 
     results = {}
-    for variant, env in (("default", {}), ("first kernel", {"PHX_ADJ": "v1"}), ("third kernel", {"PHX_ADJ": "v3"})):
-        for k in ("PHX_ADJ", "PHX_ADJ2_NP"):
+    for variant, env in (("default", {}), ("first kernel", {"PHX_ADJ": "v1", "PHX_FWD": "v1"}), ("third kernel", {"PHX_ADJ": "v3"})):
+        for k in ("PHX_ADJ", "PHX_ADJ2_NP", "PHX_FWD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -44,6 +44,11 @@ us = raw.astype(np.float64) / 100.0
 names = ["other", "P1", "syncA", "reduce", "syncB", "P2", "init(weights,y0)", "norm sync", "norm gather", "controller", "accept pass", "quad: rest", "quad: mfma+loop", "quad: loads+act", "quad: stores", "chunk weight staging"]
 kern = lib.phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS[wl["method"]]) if which == "adj" else 0
 second = kern == 2
+fwd3 = which == "fwd" and wl["method"] == "dopri5" and H <= 48 and os.environ.get("PHX_FWD") != "v1"
+if fwd3:
+    names = ["other (barriers, tails)", "sweeps: P1 only", "sweeps: fused P2+P1", "reduce-scatter", "gather hidden rows (1st tile)",
+             "sweeps: P2 only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "accept pass (dense output)",
+             "-", "-", "-", "-", "-"]
 if kern == 3:
     names = ["other (barriers, tails)", "sweeps: P1' only", "sweeps: fused P2'+P1'", "reduce-scatter (+FSAL rows)", "gather hidden rows (1st tile)",
              "sweeps: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "quadrature + accept", "-",
