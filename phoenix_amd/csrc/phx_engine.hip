@@ -1077,8 +1077,8 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
-// Full VJP of the RHS (or of prior_only_forward) on a batch, H <= 128: A -> R per row chunk, E (input VJP, f, dg
-// partials) per row chunk, C (parameter gradients) once.  Any of vjp_y / grads / f_out may be null.
+// Full VJP of the RHS (or of prior_only_forward) on a batch: per hidden chunk A -> R per row chunk, E (input VJP, f, dg
+// partials) per row chunk, C (parameter gradients) once per hidden chunk.  Any of vjp_y / grads / f_out may be null.
 template <int HT>
 int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, float *vjp_y,
                      const phx_grads *grads, float *f_out, int prior_only, char *base, hipStream_t st)
@@ -1090,22 +1090,25 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
     const bool want_e = vjp_y || f_out || (grads && full);
     if (grads && hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
     if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA) || !set_lds(k2_expand_vjp<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
-    const int hc = p->H;
-    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
-        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
-        hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA, st,
-                           to_net(p), pb.d, y, cot, part, t0, nt, 0, hc, full);
-        const int tasks = nt * HT * 4;
-        hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
-                           pb.d.G, t0, nt, pb.Kp, 0, hc, want_e ? zl4 : (float *)nullptr);
-        if (want_e)
-            hipLaunchKernelGGL((k2_expand_vjp<HT>), dim3(pb.d.TG * pb.d.G), dim3(256), pb.ldsA, st, to_net(p), pb.d, y, cot,
-                               zl4, vjp_y, f_out, (grads && full) ? dgp : (float *)nullptr, prior_only, t0, nt,
-                               t0 == 0 ? 1 : 0);
+    for (int ch = 0; ch < pb.d.HC; ++ch) {   // hidden chunks: independent slices whose contributions add up (kernel E)
+        const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
+        for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
+            const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
+                               st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc, full);
+            const int tasks = nt * HT * 4;
+            hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
+                               pb.d.G, t0, nt, pb.Kp, hb, hc, want_e ? zl4 : (float *)nullptr);
+            if (want_e)
+                hipLaunchKernelGGL((k2_expand_vjp<HT>), dim3(pb.d.TG * pb.d.G), dim3(256), pb.ldsA, st, to_net(p), pb.d, y,
+                                   cot, zl4, vjp_y, f_out, (grads && full) ? dgp : (float *)nullptr, prior_only, t0, nt,
+                                   (t0 == 0 && ch == 0) ? 1 : 0, hb, hc);
+        }
+        if (grads)
+            hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt,
+                               dth, pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc, full);
     }
     if (grads) {
-        hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
-                           pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, 0, hc, full);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
@@ -1448,9 +1451,10 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
             return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         }
     }
-    {   // everything else (dL/dy wanted, f wanted, or the full RHS): MFMA kernel chain A -> R -> E (+ C), H <= 128
+    {   // everything else (dL/dy wanted, f wanted, or the full RHS): MFMA kernel chain A -> R -> E (+ C), one pass per
+        // hidden chunk (H > 128: two chunks whose contributions add up)
         PlanBatch pb;
-        if (p->H <= 128 && plan_batch(p->N, p->H, B, &pb) && pb.d.HC == 1 && pb.d.NB <= 6) {
+        if (plan_batch(p->N, p->H, B, &pb) && pb.d.NB <= 6) {
             if (workspace_bytes < pb.total_vjp) return PHX_ERR_WORKSPACE;
             return pb.d.HT == 3 ? launch_batch_vjp<3>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st)
                                 : launch_batch_vjp<8>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st);

@@ -231,7 +231,9 @@ def rhs_forward(p, y, prior_only=False):
     return out.reshape(y.shape)
 
 
-def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True):
+def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True, f_out=None):
+    """phx_rhs_vjp on a batch; `f_out` (optional, a contiguous float32 tensor shaped like `y`) also receives f(y) --
+    the C entry point's `f_out` argument."""
     _require_gpu(y, "y")
     _require_gpu(cot, "cot")
     y2 = y.detach().reshape(-1, p.N).contiguous()
@@ -240,8 +242,13 @@ def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True):
     vjp = torch.empty_like(y2) if want_vjp_y else None
     grads = p.new_grads() if want_grads else None
     ws, nb = _workspace(_lib.OP_RHS_VJP, p.N, p.H, B, 0, y.device)
+    if f_out is not None:
+        _require_gpu(f_out, "f_out")
+        if f_out.dtype != torch.float32 or not f_out.is_contiguous() or f_out.numel() != y2.numel():
+            raise ValueError("f_out must be a contiguous float32 tensor with as many elements as y")
     _check_call(_lib.load().phx_rhs_vjp(C.byref(p.c), _p(y2), _p(c2), _p(vjp), C.byref(grads.c) if grads else None,
-                                        C.c_void_p(0), B, int(prior_only), _p(ws), nb, _stream_ptr()))
+                                        _p(f_out) if f_out is not None else C.c_void_p(0), B, int(prior_only), _p(ws), nb,
+                                        _stream_ptr()))
     return (vjp.reshape(y.shape) if want_vjp_y else None), grads
 
 

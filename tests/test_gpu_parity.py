@@ -306,7 +306,8 @@ def test_rhs_vjp_vs_oracle(pa, dev, oracle, N, H, B):
 
 
 @pytest.mark.parametrize("prior_only", [False, True])
-@pytest.mark.parametrize("N,H,B", [(11165, 40, 300), (700, 100, 37), (513, 7, 3), (2000, 128, 130)])
+@pytest.mark.parametrize("N,H,B", [(11165, 40, 300), (700, 100, 37), (513, 7, 3), (2000, 128, 130),
+                                   (700, 200, 37), (1100, 131, 130), (3000, 256, 70)])   # the last three: two hidden chunks
 def test_rhs_vjp_kernel_chain_vs_oracle_rows_and_valu_engine(pa, dev, oracle, monkeypatch, N, H, B, prior_only):
     """phx_rhs_vjp with dL/dy (the adjoint.py:116-119 shape on a whole batch) runs as the MFMA kernel chain; checked
     against the oracle on sampled rows (input VJP), against the VALU engine for everything (input VJP, all six
@@ -326,6 +327,11 @@ def test_rhs_vjp_kernel_chain_vs_oracle_rows_and_valu_engine(pa, dev, oracle, mo
     for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
         a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
         assert relerr(a, b) < 2 * TOL_RHS or (np.abs(b).max() == 0 and np.abs(a).max() == 0), k
+    # f(y) from the same chain (the C entry point's f_out) equals the forward entry point
+    fo = torch.empty_like(y)
+    v_f, _ = engine.rhs_vjp(P, y, cot, prior_only=prior_only, want_grads=False, f_out=fo)
+    assert torch.equal(v_f, vjp)
+    assert relerr(fo.cpu().numpy(), engine.rhs_forward(P, y, prior_only=prior_only).cpu().numpy()) < TOL_RHS
     # single outputs equal the combined call
     v_only, none = engine.rhs_vjp(P, y, cot, prior_only=prior_only, want_grads=False)
     assert none is None and torch.equal(v_only, vjp)
