@@ -272,6 +272,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed device pre-warm (a fresh process on an idle GPU starts at low clocks with cold caches / lazily created
+    # RCCL communicators: the first ~0.2 s of steps run up to 35 % slow).  Same step as the timed one; not counted in
+    # `warmup` or `steps`, the same number of steps on every rank.
+    n_pre = {"breast": 200, "insilico": 200, "yeast": 30}.get(args.workload, 5)   # ~0.2-0.3 s each, fixed => rank-uniform
+    for _ in range(n_pre):
+        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
+    sync_all()
     for _ in range(args.warmup):
         one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
     sync_all()
