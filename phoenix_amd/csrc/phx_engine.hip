@@ -793,6 +793,11 @@ constexpr size_t ADJ_LDS_EXTRA = 0;
 constexpr int ADJ_NW_CAP = 4;   // the augmented kernel needs the 512-register budget of one wave per SIMD
 
 
+// hidden-fragment tiles of the solve kernels: 3 for a narrow hidden layer, 8 (128 rows) otherwise -- except for a chunked
+// hidden layer whose chunks need only 7 tiles (96 < Hc <= 112; the B-cell shape: H = 200 -> 2 x 100), where the eighth
+// tile would be 12.5 % of the MFMAs, exchange rows and quadrature accumulators spent on padding
+inline int solve_ht(int HC, int Hc) { return Hc <= 48 ? 3 : ((HC > 1 && Hc <= 112) ? 7 : 8); }
+
 // picks (NW, TPW, NB): minimise the per-wave MFMA work TPW*NB subject to LDS and residency
 bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hidden frag tiles / HT */,
              size_t lds_per_block_extra, D1 *out, size_t ctl_extra_per_traj = 0, int nw_cap = 8, int calls = 1)
@@ -804,7 +809,7 @@ bool plan_v1(int N, int H, int B, int T, int control, int nvec, int fwidth /* hi
     if (cus <= 0 || force_v0()) return false;
     // H > 128: the hidden layer is cut into HC chunks of Hc <= 128 rows whose weights take turns in LDS
     const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;
-    const int HT = Hc <= 48 ? 3 : 8;
+    const int HT = solve_ht(HC, Hc);
     if (HC > 1) nvec += (nvec >= NVEC_ADJ) ? (NVEC_ADJ_CH - NVEC_ADJ) : (NVEC_FWD_CH - NVEC_FWD);
     const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4 + lds_per_block_extra;
     const int nblk = (N + 31) / 32, ntt = ((Bcall ? Bcall : B) + 15) / 16;
@@ -1324,14 +1329,14 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
 size_t phx_weight_image_bytes(int N, int H)
 {
     if (N <= 0 || H <= 0 || H > 256 || force_v0()) return 0;
-    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC, HT = Hc <= 48 ? 3 : 8;
+    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC, HT = solve_ht(HC, Hc);
     return (size_t)((N + 31) / 32) * HC * blk_floats_ch(HT, Hc) * 4;
 }
 
 int phx_pack_weight_images(const phx_params *p, void *wimg, void *stream)
 {
     if (bad_params(p) || !wimg || phx_weight_image_bytes(p->N, p->H) == 0) return PHX_ERR_BAD_ARG;
-    const int HC = (p->H + 127) / 128, Hc = (p->H + HC - 1) / HC, HT = Hc <= 48 ? 3 : 8;
+    const int HC = (p->H + 127) / 128, Hc = (p->H + HC - 1) / HC, HT = solve_ht(HC, Hc);
     hipLaunchKernelGGL(k1_pack_images, dim3(((p->N + 31) / 32) * HC), dim3(256), 0, (hipStream_t)stream, to_net(p),
                        (float *)wimg, HT, HC, Hc, blk_floats_ch(HT, Hc));
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
@@ -1529,7 +1534,11 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
                 hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
-            if (d1.HC > 1) {
+            if (d1.HC > 1 && d1.HT == 7) {
+                if (!set_lds_resident(k1_solve_fwd<7, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_fwd<7, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
+                                   sol, status, nfe, nsteps);
+            } else if (d1.HC > 1) {
                 if (!set_lds_resident(k1_solve_fwd<8, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_fwd<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t,
                                    sol, status, nfe, nsteps);
@@ -1625,7 +1634,11 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
                 hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk * d1.HC), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT,
                                    d1.HC, d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
             ev_begin(st);
-            if (d1.HC > 1) {
+            if (d1.HC > 1 && d1.HT == 7) {
+                if (!set_lds_resident(k1_solve_adj<7, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
+                hipLaunchKernelGGL((k1_solve_adj<7, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
+                                   y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
+            } else if (d1.HC > 1) {
                 if (!set_lds_resident(k1_solve_adj<8, 256, true>, lds, (int)blk1.x, (int)grid1.x)) return PHX_ERR_LAUNCH;
                 hipLaunchKernelGGL((k1_solve_adj<8, 256, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t,
                                    y_saved, grad_y, adj_y0, status, nfe, nsteps, grads ? 1 : 0, PP);
