@@ -35,10 +35,11 @@ bool plan_fwd3(int N, int H, int B, int T, int control, int method, D1 *out)
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
-    // One wave per SIMD (NW <= 4).  The eight-wave form (two waves per SIMD under a 256-register cap) needs scratch
-    // spills, and with them trajectories 12..15 of the tiles of waves 4..7 came out with wrong error norms as soon as a
-    // launch had more than 1024 waves (TG x G > 128 workgroups; measured with tools/fwd3_check.py) -- not understood,
-    // so that form is not built.  Four waves are faster than k1_solve_fwd's eight at C4 anyway (0.27 vs 0.29 ms).
+    // One wave per SIMD (NW <= 4).  The eight-wave form (two waves per SIMD under a 256-register cap) computed wrong
+    // step sizes for the trajectories 12..15 of the tiles 4..7 of a group as soon as a group had more than 64 gene tiles
+    // (tools/fwd3_check.py; not the private segment, not the out-of-line controller math: DESIGN.md section 2, "one
+    // signature") -- not understood, so that form is not built.  Four waves are faster than k1_solve_fwd's eight at C4
+    // anyway (0.26 vs 0.29 ms).
     int nwmax = 4;
     if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
     for (int NW = nwmax; NW >= 1; NW >>= 1)
