@@ -821,11 +821,14 @@ def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant
         assert relerr(gg[k], gr_ref[k]) < gtol, k
 
 
-def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle):
+@pytest.mark.parametrize("N,H,B,adj", [(300, 10, 5, None), (300, 10, 5, "v3"), (1500, 12, 20, None), (1500, 12, 37, "v1")])
+def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle, monkeypatch, N, H, B, adj):
     """odeint_adjoint on a batched y0 with ONE controller (reference semantics) over several output times:
-    exercises the per-interval restarts, the jump a += grad_y[i-1] and the multi-step quadrature."""
-    N, H, B = 300, 10, 5
-    p = rand_params(N, H, seed=17, std=0.15)
+    exercises the per-interval restarts, the jump a += grad_y[i-1] and the multi-step quadrature -- on the kernel the
+    shape gets (300 genes: the wave-pair kernel; 1500 genes = 47 gene tiles: the third kernel) and on a forced one."""
+    if adj:
+        monkeypatch.setenv("PHX_ADJ", adj)
+    p = rand_params(N, H, seed=17, std=0.15 if N == 300 else 0.05)
     net, onet = make_net(pa, dev, p), onet_of(oracle, p)
     r = np.random.RandomState(5)
     y0 = (r.rand(B, 1, N) * 1.4 - 0.2).astype(np.float32)
