@@ -359,7 +359,7 @@ def test_per_sample_solve_and_adjoint_vs_oracle(pa, dev, oracle, method, N, H, B
     t = np.stack([np.array([0.1 * b, 0.1 * b + 0.4 + 0.05 * (b % 64)]) for b in range(B)]).astype(np.float32)
     G = r.randn(B, 2, N).astype(np.float32)
     ref = oracle.odeint_per_sample(onet, y0, t, method=method)                       # [B,2,N]
-    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=False)
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=True)
     y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)    # [2,B,1,N]
     got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
@@ -464,7 +464,7 @@ def test_full_size_breast_properties(pa, dev, oracle):
     ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
     adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
-                                                          method="dopri5", theta_in_norm=False)
+                                                          method="dopri5", theta_in_norm=True)
     assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     full = grads_of(net)
     # parameter gradients at full size against the oracle: the engine on exactly the sampled rows (the quadrature
@@ -570,7 +570,7 @@ def test_full_size_insilico_vs_oracle(pa, dev, oracle):
     t = np.tile(np.array([[0.0, 2.0, 3.0, 7.0, 9.0]], np.float32), (B, 1))
     G = (r.randn(B, 5, N) / (B * N)).astype(np.float32)
     ref = oracle.odeint_per_sample(onet, y0, t, method="rk4")
-    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="rk4", theta_in_norm=False)
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="rk4", theta_in_norm=True)
     y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method="rk4")
     got = sol.detach().cpu().numpy().reshape(5, B, N).transpose(1, 0, 2)
@@ -631,7 +631,7 @@ def test_full_size_bcell_properties(pa, dev, oracle):
     ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
     adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
-                                                          method="dopri5", theta_in_norm=False)
+                                                          method="dopri5", theta_in_norm=True)
     assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     full = grads_of(net)
     zero_grads(net)                                  # parameter gradients of exactly the sampled rows against the oracle
@@ -807,7 +807,7 @@ def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant
     t = np.stack([np.array([0.05 * b, 0.05 * b + 0.5]) for b in range(B)]).astype(np.float32)
     G = r.randn(B, 2, N).astype(np.float32)
     ref = oracle.odeint_per_sample(onet, y0, t, method=method)
-    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=False)
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method=method, theta_in_norm=True)
     y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev), method=method)
     got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
@@ -835,7 +835,7 @@ def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle, monkey
     t = np.array([0.0, 0.6, 1.1, 2.5], np.float32)
     G = r.randn(4, B, 1, N).astype(np.float32)
     ref = oracle.odeint(onet, y0, t, method="dopri5")
-    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method="dopri5", theta_in_norm=True)
     y0t = torch.from_numpy(y0).to(dev).requires_grad_(True)
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
     assert relerr(sol.detach().cpu().numpy(), ref) < TOL_DOPRI
@@ -859,7 +859,7 @@ def test_chunked_hidden_layer_shared_control_vs_oracle(pa, dev, oracle, N, H, B,
     t = np.array([0.0, 0.4, 0.9, 1.3], np.float32)
     G = r.randn(4, B, 1, N).astype(np.float32)
     ref = oracle.odeint(onet, y0, t, method=method)
-    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method=method, theta_in_norm=False)
+    adj_ref, gr_ref = oracle.adjoint_backward(onet, t, ref, G, method=method, theta_in_norm=True)
     tol, gtol = (TOL_DOPRI, TOL_DOPRI_GRAD) if method == "dopri5" else (TOL_FIXED, TOL_FIXED)
     results = {}
     for engine in ("v1", "v0"):
@@ -897,7 +897,7 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
         t = np.tile(np.array([[0.0, 0.8]], np.float32), (B, 1))
         G = r.randn(B, 2, N).astype(np.float32)
         ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
-        adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=False)
+        adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
         y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
         sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
         got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
