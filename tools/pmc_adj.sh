@@ -16,7 +16,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "adj3" if "k1_solve_adj3" in k else ("adj2" if "k1_solve_adj2" in k else ("adj1" if "k1_solve_adj" in k else ("fwd" if "k1_solve_fwd" in k else None)))
+        name = "adj3" if "k1_solve_adj3" in k else ("adj2" if "k1_solve_adj2" in k else ("adj1" if "k1_solve_adj" in k else ("fwd3" if "k1_solve_fwd3" in k else ("fwd" if "k1_solve_fwd" in k else None))))
         if not name: continue
         tot[name][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[name][r["Counter_Name"]] += 1
 for name in tot:
