@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 4
+#define PHX_ABI_VERSION 5
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -154,6 +154,20 @@ int phx_prior_targets_sell(const long long *sptr, const int *width, const int *r
  * cannot be planned (the caller then evaluates the unfused formula).                                              */
 int phx_prior_mse(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same step with the hidden rows kept for the backward (ABI 5).  The forward chain of phx_prior_mse reduces the
+ * hidden rows z = [Ws a(X) + bs ; exp(Wp l(X) + bp)] of every row of X anyway; phx_prior_mse_save also writes them to
+ * `z_save` (phx_prior_z_bytes(N, H, B) bytes, device, caller-owned; 0 = this shape has no such path: H > 128 or the
+ * batch chain cannot be planned), and phx_prior_vjp_saved computes the parameter gradients of
+ * sum(cot * prior_only_forward(X)) -- what phx_rhs_vjp(prior_only = 1, vjp_y = NULL) computes -- WITHOUT recomputing
+ * them: its first kernel contracts only the cotangent (half the MFMAs and partial rows).  Same workspaces as
+ * phx_prior_mse / phx_rhs_vjp.  Replaces nothing new in the reference: it is train_insilico.py:134-138 again, with
+ * autograd's saved activations made explicit.                                                                       */
+size_t phx_prior_z_bytes(int N, int H, int B);
+int phx_prior_mse_save(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
+                       float *z_save, void *workspace, size_t workspace_bytes, void *stream);
+int phx_prior_vjp_saved(const phx_params *p, const float *X, const float *cot, const float *z_saved,
+                        const phx_grads *grads, int B, void *workspace, size_t workspace_bytes, void *stream);
 
 /* the ground-truth Hill-kinetics simulator behind the reference's in-silico data
  * (GraphGRN_core.R:425-486 emits one rate expression per gene -- ode_system_functions_*.csv -- and

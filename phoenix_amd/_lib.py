@@ -28,7 +28,7 @@ EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_worksp
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
            "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell",
-           "phx_debug_adjoint_kernel_m")
+           "phx_debug_adjoint_kernel_m", "phx_prior_z_bytes", "phx_prior_mse_save", "phx_prior_vjp_saved")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -76,6 +76,10 @@ def load():
     lib.phx_prior_targets.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.phx_prior_targets_sell.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.phx_prior_mse.argtypes = [C.POINTER(PhxParams), vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp]
+    lib.phx_prior_z_bytes.restype = C.c_size_t
+    lib.phx_prior_z_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.phx_prior_mse_save.argtypes = [C.POINTER(PhxParams), vp, vp, C.c_int, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.phx_prior_vjp_saved.argtypes = [C.POINTER(PhxParams), vp, vp, vp, C.POINTER(PhxGrads), C.c_int, vp, C.c_size_t, vp]
     lib.phx_hill_rhs.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.phx_hill_simulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, C.c_int, vp]
     lib.phx_debug_set_kernel_events.argtypes = [vp, vp]
@@ -87,6 +91,6 @@ def load():
     lib.phx_weight_image_bytes.argtypes = [C.c_int, C.c_int]
     lib.phx_weight_image_bytes.restype = C.c_size_t
     lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
-    assert lib.phx_abi_version() == 4
+    assert lib.phx_abi_version() == 5
     _LIB = lib
     return lib

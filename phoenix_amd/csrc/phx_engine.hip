@@ -1048,28 +1048,31 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     return true;
 }
 
+
+// zsaved (optional, unchunked hidden layer only): the reduced hidden rows the forward chain of the same step kept
+// (phx_prior_mse_save) -- kernel A then contracts the cotangent only (half its MFMAs and partial rows)
 template <int HT>
 int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
-                       char *base, hipStream_t st);
-
-
-template <int HT>
-int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
-                       char *base, hipStream_t st)
+                       char *base, hipStream_t st, const float *zsaved = nullptr)
 {
+    if (pb.d.HC != 1) zsaved = nullptr;
     float *part = (float *)(base + pb.part), *hdt = (float *)(base + pb.hdt), *dth = (float *)(base + pb.dtheta);
     const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
     if (hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
-    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA) || !set_lds(k2_hidden_partials<HT, 2>, pb.ldsA)) return PHX_ERR_LAUNCH;
     for (int ch = 0; ch < pb.d.HC; ++ch) {      // hidden chunks are independent slices of the same gradient
         const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
         for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
             const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
-            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
-                               st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
+            if (zsaved)
+                hipLaunchKernelGGL((k2_hidden_partials<HT, 2>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
+                                   st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
+            else
+                hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256),
+                                   pb.ldsA, st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
-                               pb.d.G, t0, nt, pb.Kp, hb, hc);
+                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, const_cast<float *>(zsaved));
         }
         hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
                            pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc);
@@ -1129,8 +1132,9 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
 // prior_only_forward / ODENet.forward on a large batch: A (u, v partials) -> R (z rows) -> D (expansion) per chunk
 template <int HT>
 int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *y, float *out, int prior_only, char *base,
-                         hipStream_t st, const float *target = nullptr, float *loss = nullptr)
+                         hipStream_t st, const float *target = nullptr, float *loss = nullptr, float *zsave = nullptr)
 {
+    if (pb.d.HC != 1) zsave = nullptr;   // (the saved rows are those of an unchunked hidden layer)
     float *part = (float *)(base + pb.part), *zl = (float *)(base + pb.zl);
     double *loss_part = (double *)(base + pb.losspart);
     const float cot_scale = (float)(2.0 / ((double)pb.d.B * (double)p->N));
@@ -1146,7 +1150,7 @@ int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *
                                (const float *)nullptr, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
-                               pb.d.G, t0, nt, pb.Kp, hb, hc);
+                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, zsave);
             hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt, hb,
                                hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0, target, cot_scale, loss_part);
         }
@@ -1214,6 +1218,38 @@ int phx_prior_mse(const phx_params *p, const float *X, const float *target, int 
     hipStream_t st = (hipStream_t)stream;
     return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, X, cot, 1, (char *)workspace, st, target, loss)
                         : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss);
+}
+
+size_t phx_prior_z_bytes(int N, int H, int B)
+{
+    PlanBatch pb;
+    if (N <= 0 || H <= 0 || B <= 0 || !plan_batch(N, H, B, &pb) || pb.d.HC != 1) return 0;
+    return (size_t)pb.ntiles * 2 * pb.d.HT * 4 * 64 * sizeof(float);
+}
+
+int phx_prior_mse_save(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
+                       float *z_save, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !X || !target || !cot || !loss || !z_save || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    PlanBatch pb;
+    if (!plan_batch(p->N, p->H, B, &pb) || pb.d.HC != 1) return PHX_ERR_BAD_ARG;
+    if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save)
+                        : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save);
+}
+
+int phx_prior_vjp_saved(const phx_params *p, const float *X, const float *cot, const float *z_saved, const phx_grads *grads,
+                        int B, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (bad_params(p) || !X || !cot || !z_saved || !grads || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
+    if (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g) return PHX_ERR_BAD_ARG;
+    PlanBatch pb;
+    if (!plan_batch(p->N, p->H, B, &pb) || pb.d.HC != 1) return PHX_ERR_BAD_ARG;
+    if (workspace_bytes < pb.total) return PHX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    return pb.d.HT == 3 ? launch_batch_pgrad<3>(pb, p, X, cot, grads, (char *)workspace, st, z_saved)
+                        : launch_batch_pgrad<8>(pb, p, X, cot, grads, (char *)workspace, st, z_saved);
 }
 
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out, int K, int N,

@@ -255,9 +255,11 @@ def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True, f_out
 PRIOR_MSE_MIN_ROWS = 1024   # BATCH_FWD_MIN_ROWS of the library: below it the workspace query does not cover the chain
 
 
-def prior_mse(p, X, target):
-    """fused mean((prior_only_forward(X) - target)^2) and its cotangent; returns (loss [1], cot like X) or None when
-    the engine cannot plan the batch chain for this shape (caller falls back to the unfused formula)."""
+def prior_mse(p, X, target, keep_hidden=False):
+    """fused mean((prior_only_forward(X) - target)^2) and its cotangent; returns (loss [1], cot like X) -- with
+    `keep_hidden` (loss, cot, z): z = the reduced hidden rows of the forward chain for `prior_vjp_saved`, or None where
+    the library has no such path (H > 128) -- or None when the engine cannot plan the batch chain for this shape
+    (caller falls back to the unfused formula)."""
     _require_gpu(X, "X")
     _require_gpu(target, "target")
     x2 = X.detach().reshape(-1, p.N).contiguous()
@@ -268,11 +270,34 @@ def prior_mse(p, X, target):
     cot = torch.empty_like(x2)
     loss = torch.empty(1, dtype=torch.float32, device=x2.device)
     ws, nb = _workspace(_lib.OP_RHS_FORWARD, p.N, p.H, B, 0, X.device)
-    rc = _lib.load().phx_prior_mse(C.byref(p.c), _p(x2), _p(t2), B, _p(cot), _p(loss), _p(ws), nb, _stream_ptr())
+    zbytes = _lib.load().phx_prior_z_bytes(p.N, p.H, B) if keep_hidden else 0
+    if zbytes:
+        z = torch.empty(zbytes // 4, dtype=torch.float32, device=x2.device)
+        rc = _lib.load().phx_prior_mse_save(C.byref(p.c), _p(x2), _p(t2), B, _p(cot), _p(loss), _p(z), _p(ws), nb,
+                                            _stream_ptr())
+    else:
+        z = None
+        rc = _lib.load().phx_prior_mse(C.byref(p.c), _p(x2), _p(t2), B, _p(cot), _p(loss), _p(ws), nb, _stream_ptr())
     if rc == 4:
         return None
     _check_call(rc)
-    return loss, cot
+    return (loss, cot, z) if keep_hidden else (loss, cot)
+
+
+def prior_vjp_saved(p, X, cot, z):
+    """parameter gradients of sum(cot * prior_only_forward(X)) from the hidden rows `z` that `prior_mse(...,
+    keep_hidden=True)` kept (phx_prior_vjp_saved): what rhs_vjp(prior_only=True, want_vjp_y=False) returns, without
+    recomputing the hidden layer."""
+    _require_gpu(X, "X")
+    _require_gpu(cot, "cot")
+    x2 = X.detach().reshape(-1, p.N).contiguous()
+    c2 = cot.detach().reshape(-1, p.N).contiguous()
+    B = x2.shape[0]
+    grads = p.new_grads()
+    ws, nb = _workspace(_lib.OP_RHS_VJP, p.N, p.H, B, 0, X.device)
+    _check_call(_lib.load().phx_prior_vjp_saved(C.byref(p.c), _p(x2), _p(c2), _p(z), C.byref(grads.c), B, _p(ws), nb,
+                                                _stream_ptr()))
+    return grads
 
 
 def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls=1):

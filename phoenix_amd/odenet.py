@@ -70,18 +70,22 @@ class _PriorMSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, target, ws, bs, wp, bp, wa, g):
         p = engine.params_cached(ws, bs, wp, bp, wa, g)
-        res = engine.prior_mse(p, X, target)
+        res = engine.prior_mse(p, X, target, keep_hidden=True)
         if res is None:
             raise RuntimeError("phoenix_amd: the fused prior loss is not available for this shape / engine mode")
-        loss, cot = res
-        ctx.save_for_backward(X, cot, ws, bs, wp, bp, wa, g)
+        loss, cot, z = res
+        ctx.has_z = z is not None          # the forward chain's hidden rows, kept for the backward (no recomputation)
+        ctx.save_for_backward(X, cot, ws, bs, wp, bp, wa, g, *([z] if z is not None else []))
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        X, cot, ws, bs, wp, bp, wa, g = ctx.saved_tensors
+        X, cot, ws, bs, wp, bp, wa, g = ctx.saved_tensors[:8]
         p = engine.params_cached(ws, bs, wp, bp, wa, g)
-        _, grads = engine.rhs_vjp(p, X, cot, True, want_grads=True, want_vjp_y=False)
+        if ctx.has_z:
+            grads = engine.prior_vjp_saved(p, X, cot, ctx.saved_tensors[8])
+        else:
+            _, grads = engine.rhs_vjp(p, X, cot, True, want_grads=True, want_vjp_y=False)
         grads.flat.mul_(grad_out)          # the cotangent was formed for d loss = 1
         gws, gbs, gwp, gbp, gwa, gg = grads.as_reference_layout(g.shape)
         return None, None, gws, gbs, gwp, gbp, gwa, gg

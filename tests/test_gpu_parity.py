@@ -909,6 +909,28 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
             assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
+@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 1100), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100)])
+def test_prior_backward_from_saved_hidden_rows_equals_recomputation(pa, dev, N, H, K):
+    """phx_prior_mse_save + phx_prior_vjp_saved (the forward chain's hidden rows kept for the backward) give the bits of
+    phx_prior_mse + phx_rhs_vjp (which recomputes them); for H > 128 there is no saved path and the mirror falls back."""
+    from phoenix_amd import engine
+    p = rand_params(N, H, seed=5 * N + H, std=0.08)
+    net = make_net(pa, dev, p)
+    P = engine.params_cached(*pa.odenet.params_of(net))
+    r = np.random.RandomState(3)
+    X = torch.from_numpy((r.rand(K, N) - 0.5).astype(np.float32)).to(dev)
+    tgt = torch.from_numpy((r.randn(K, N) * 0.1).astype(np.float32)).to(dev)
+    loss0, cot0 = engine.prior_mse(P, X, tgt)
+    loss1, cot1, z = engine.prior_mse(P, X, tgt, keep_hidden=True)
+    assert torch.equal(loss0, loss1) and torch.equal(cot0, cot1)
+    assert (z is None) == (H > 128)
+    _, g0 = engine.rhs_vjp(P, X, cot0, True, want_grads=True, want_vjp_y=False)
+    if z is not None:
+        g1 = engine.prior_vjp_saved(P, X, cot1, z)
+        for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+            assert torch.equal(getattr(g0, k), getattr(g1, k)), k
+
+
 @pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100), (300, 131, 90)])
 def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the exchange-free
