@@ -3,13 +3,20 @@
 
 One "step" = one pass of the hot path over one batch of synthetic trajectories:
     forward  odeint(ODENet, y0[B,1,N], t[B,2])       (one persistent launch, all samples)
-  + backward OdeintAdjointMethod.backward            (one persistent launch, all samples)
-  + (N GPUs > 1) one flat RCCL all-reduce of the P = 4HN+2H+N gradient floats.
+  + backward OdeintAdjointMethod.backward            (one persistent launch, all samples), entered through autograd
+             with the loss cotangent dL/dsol handed to `torch.autograd.backward` (a loss head is not part of the path;
+             the reference's own two losses are timed in the separate `training_step` object)
+  + the per-step parameter re-layout a real optimizer step forces (version bump) + the gradient reduction kernel
+  + (N GPUs > 1) one grouped RCCL all-reduce of the P = 4HN+2H+N gradient floats.
 Default workload = BASELINE.json config C4 (the one the north-star target is quoted on):
 breast-cancer scale N=11165 genes, H=40, 256 trajectory intervals per GPU, dopri5 rtol 1e-7 / atol 1e-9.
-Default = weak scaling: every rank integrates its own 256 trajectories (no data-path collective).
-`--scaling strong`: the 256 trajectories of the workload are sharded over the ranks (BASELINE.json config 4:
-"256 trajectory batch sharded 1/2/4/8"), the loss is normalised by the GLOBAL batch.
+
+`--gpus N` with N > 1 and no RANK in the environment: this process starts N ranks itself (torch.distributed.run as a
+child, one rank per device, before anything touches a GPU) and exits with the child's code; rank 0 prints the line.
+Scaling: N = 1 and `--scaling weak` (default): every rank integrates its own 256 trajectories (no data-path collective).
+With N > 1 the default also measures BASELINE.json config 4 as written -- "256 trajectory batch sharded 1/2/4/8" --
+in the same run: `extra.strong` holds the step time / rate of the ONE 256-trajectory batch sharded over the ranks (loss
+normalised by the GLOBAL batch); `--scaling strong` makes that the headline instead.
 
 Metric: gene x trajectory RHS evaluations per second = sum over samples of (forward NFE + augmented NFE) * N / time.
 Prints ONE JSON line (rank 0).
@@ -72,7 +79,7 @@ def one_step(net, y0, t, G, method, world):
         torch.autograd.graph.increment_version(p)
     y = y0.detach().requires_grad_(True)
     sol = phoenix_amd.odeint_adjoint(net, y, t, method=method)
-    (sol * G).sum().backward()
+    torch.autograd.backward(sol, G)          # G = dL/dsol [T,B,1,N]: the backward solve is entered with it as it is
     if world > 1:
         parallel.allreduce_grads(net)
     return sol
@@ -208,7 +215,7 @@ def full_training_step_ms(wl, net, y0, t, device, K=10000, reps=5):
     return float(np.median(times[2:]))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -218,21 +225,110 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="profiling runs: only the timed loop and the per-kernel timing (no training step, no "
                          "strong-scaling shards: their launches would be averaged into the per-kernel profile)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="default: weak is the headline; with more than one rank the sharded (strong) problem is "
+                         "measured in the same run and reported under extra.strong")
     ap.add_argument("--status", default="deferred", choices=["deferred", "immediate"],
-                    help="solver status read-back: behind the backward kernel (checked at a later engine call) or a "
-                         "blocking round trip at the end of every backward()")
+                    help="solver status read-back: behind the backward kernel (checked at a later engine call; the "
+                         "library default) or a blocking round trip at the end of every backward()")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="diagnostic, single process only: with --scaling strong, integrate rank 0's shard of a run with "
                          "this many ranks (what ONE GPU of that run would do per step)")
-    args = ap.parse_args()
+    ap.add_argument("--prewarm-seconds", type=float, default=2.0,
+                    help="untimed device pre-warm before the W warm-up steps, as a number of steps fixed per workload "
+                         "from this many seconds (rank-uniform); 0 disables it")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = PLUMBING TEST ONLY (CPU, tests/test_bench_cpu.py): rank spawning, barriers, the gradient "
+                         "all-reduce and the output line with a stub in place of the engine; prints value null")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start the N ranks as a child torch.distributed.run BEFORE this process touches a
+    GPU (device_count() does not initialise one) and hand its exit code on.  The child ranks inherit stdout, rank 0
+    prints the one JSON line."""
+    import socket
+    import subprocess
+    if args.backend == "nccl":
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, ndev))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, rank, world):
+    """--backend gloo: everything around the engine (process group, barriers, max-over-ranks timing, grouped gradient
+    all-reduce, one line from rank 0) with a CPU stub as the step.  Not a measurement: value is null."""
+    import torch.distributed as dist
+    from phoenix_amd import parallel
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 8)
+    x = torch.ones(4, 8) * (rank + 1)
+
+    def step():
+        for p in lin.parameters():
+            p.grad = None
+        lin(x).sum().backward()
+        parallel.allreduce_grads(lin)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    gsum = float(lin.bias.grad.sum())          # 8 outputs x 4 rows x world ranks
+    if rank == 0:
+        out = {"metric": "ODE-RHS evals/sec (genes x trajectories)", "value": None, "unit": "gene*trajectory RHS evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(te) / args.steps * 1e3,
+               "higher_is_better": True, "scaling": args.scaling or "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "stub (gloo plumbing test: no engine, no GPU)", "stub": True,
+               "config": {"workload": "stub", "parallelism": "trajectory-sharded x%d, grouped gradient all-reduce" % world},
+               "extra": {"allreduce_check": gsum == 8.0 * 4 * world}}
+        os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def timed_region(step, sync_all, steps, engine, use_dist, device):
+    """barrier + synchronize, exactly `steps` steps (every solve's status checked inside), barrier + synchronize;
+    returns the MAX over ranks of the elapsed seconds"""
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    engine.check_pending_status(wait=True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        import torch.distributed as dist
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed
+
+
+def main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # under torchrun (RANK set) the collective path is always taken, also with a single rank, so that a 1-GPU
     # box exercises exactly the code the 8-GPU run uses (RCCL init, barrier, flat gradient all-reduce)
     use_dist = "RANK" in os.environ
+    if args.backend == "gloo":
+        return stub_main(args, rank, world)
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -241,30 +337,39 @@ def main():
     torch.cuda.set_device(device)
 
     import phoenix_amd  # noqa: F401  (fails loudly if the HIP library is missing)
-    from phoenix_amd import engine
+    from phoenix_amd import engine, parallel
 
     engine.set_status_mode(args.status)
     wl = WORKLOADS[args.workload]
-    N, H, B = wl["N"], wl["H"], wl["B"]
-    B_global = B * world
-    if args.scaling == "strong":
-        # the SAME 256-trajectory problem at every world size, sharded over the ranks (contiguous chunks)
-        from phoenix_amd import parallel
-        net, y0, t = make_problem(wl, device, seed=0)
-        lo, hi = parallel.shard_range(B, rank, world if world > 1 or not args.shard_of else args.shard_of)
-        y0, t = y0[lo:hi].contiguous(), t[lo:hi].contiguous()
-        B_global, B = B, hi - lo
-    else:
-        net, y0, t = make_problem(wl, device, seed=rank)      # every rank its own trajectories
-    if use_dist:   # replicas share parameters
-        import torch.distributed as dist
-        for p in net.parameters():
-            dist.broadcast(p.data, 0)
+    N, H, Bw = wl["N"], wl["H"], wl["B"]
+    headline = args.scaling or "weak"
+
+    def problem(scaling):
+        """(net, y0, t, G, B_local, B_global) of one scaling mode"""
+        if scaling == "strong":
+            # the SAME 256-trajectory problem at every world size, sharded over the ranks (contiguous chunks)
+            net, y0, t = make_problem(wl, device, seed=0)
+            lo, hi = parallel.shard_range(Bw, rank, world if world > 1 or not args.shard_of else args.shard_of)
+            y0, t = y0[lo:hi].contiguous(), t[lo:hi].contiguous()
+            B_global, B = Bw, hi - lo
+        else:
+            net, y0, t = make_problem(wl, device, seed=rank)      # every rank its own trajectories
+            B_global, B = Bw * world, Bw
+        if use_dist:   # replicas share parameters
+            import torch.distributed as dist
+            for p in net.parameters():
+                dist.broadcast(p.data, 0)
+        T = t.shape[1]
+        gg = torch.Generator(device="cpu").manual_seed(100 + rank)
+        # cotangent of a mean-type loss over the GLOBAL batch (reference torch.mean over the whole batch,
+        # train_insilico.py:132)
+        G = (torch.randn(T, B, 1, N, generator=gg) / (B_global * N)).to(device)
+        G[0].zero_()
+        return net, y0, t, G, B, B_global
+
+    net, y0, t, G, B, B_global = problem(headline)
     T = t.shape[1]
-    gg = torch.Generator(device="cpu").manual_seed(100 + rank)
-    # cotangent of a mean-type loss over the GLOBAL batch (reference torch.mean over the whole batch, train_insilico.py:132)
-    G = (torch.randn(T, B, 1, N, generator=gg) / (B_global * N)).to(device)
-    G[0].zero_()
+    wdist = 2 if use_dist else 1
 
     def sync_all():
         if use_dist:
@@ -272,30 +377,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed device pre-warm (a fresh process on an idle GPU starts at low clocks with cold caches / lazily created
-    # RCCL communicators: the first ~0.2 s of steps run up to 35 % slow).  Same step as the timed one; not counted in
-    # `warmup` or `steps`, the same number of steps on every rank.
-    n_pre = {"breast": 200, "insilico": 200, "yeast": 30}.get(args.workload, 5)   # ~0.2-0.3 s each, fixed => rank-uniform
-    for _ in range(n_pre):
-        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
-    sync_all()
+    def step():
+        one_step(net, y0, t, G, wl["method"], wdist)
+
+    # Untimed device pre-warm.  A fresh process on an idle GPU starts at low clocks with cold caches, lazily created RCCL
+    # communicators and a growing caching allocator, and a 20-step timed region is ~20 ms: the pre-warm runs the same
+    # step for `--prewarm-seconds` (a step count fixed per workload => the same on every rank; not counted in `warmup`
+    # or `steps`), in windows whose per-step times go into the line (extra.prewarm_windows_ms) so that a ramp is visible.
+    nominal_ms = {"breast": 1.0, "insilico": 1.0, "yeast": 10.0, "bcell": 50.0}[args.workload]
+    n_pre = int(args.prewarm_seconds * 1e3 / nominal_ms)
+    pre_windows = []
+    win = max(1, min(100, n_pre // 10 if n_pre >= 10 else 1))
+    done = 0
+    while done < n_pre:
+        k = min(win, n_pre - done)
+        pre_windows.append(timed_region(step, sync_all, k, engine, use_dist, device) / k * 1e3)
+        done += k
     for _ in range(args.warmup):
-        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
-    sync_all()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(net, y0, t, G, wl["method"], 2 if use_dist else 1)
-    engine.check_pending_status(wait=True)       # every solve of the timed region is checked inside it
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    engine.set_status_mode("immediate")
-    if use_dist:
-        import torch.distributed as dist
-        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        step()
+    elapsed = timed_region(step, sync_all, args.steps, engine, use_dist, device)
+    # the same region five more times: how far single windows of K steps scatter on this box (p50 / p90)
+    windows = [elapsed / args.steps * 1e3]
+    for _ in range(5):
+        windows.append(timed_region(step, sync_all, args.steps, engine, use_dist, device) / args.steps * 1e3)
 
     # ---- per-kernel timing with HIP events on the launch stream + NFE accounting (rank-local)
+    engine.set_status_mode("immediate")
     p = engine.Params(net.net_sums.linear_out.weight, net.net_sums.linear_out.bias, net.net_prods.linear_out.weight,
                       net.net_prods.linear_out.bias, net.net_alpha_combine.linear_out.weight, net.gene_multipliers)
     from phoenix_amd import _lib
@@ -326,16 +433,43 @@ def main():
     nfe_aug = int(nfe_b.sum().item())
     fwd_ms_avg, adj_ms_avg = float(np.mean(fwd_ms)), float(np.mean(adj_ms))
 
-    # whole-job value
-    evals_per_step = (nfe_fwd + nfe_aug) * N      # gene x trajectory evaluations on this rank
-    if use_dist:
+    def whole_job(evals_rank):
+        if not use_dist:
+            return float(evals_rank)
         import torch.distributed as dist
-        te = torch.tensor([float(evals_per_step)], device=device, dtype=torch.float64)
+        te = torch.tensor([float(evals_rank)], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.SUM)
-        total_evals_per_step = float(te.item())
-    else:
-        total_evals_per_step = float(evals_per_step)
+        return float(te.item())
+
+    # whole-job value
+    total_evals_per_step = whole_job((nfe_fwd + nfe_aug) * N)      # gene x trajectory evaluations, all ranks
     value = total_evals_per_step * args.steps / elapsed
+
+    # ---- the other scaling mode in the same run (more than one rank, no explicit --scaling): config 4 as written
+    other = None
+    if world > 1 and args.scaling is None and not args.no_extras:
+        engine.set_status_mode(args.status)
+        net2, y02, t2, G2, B2, _ = problem("strong")
+
+        def step2():
+            one_step(net2, y02, t2, G2, wl["method"], wdist)
+
+        for _ in range(max(args.warmup, 20)):
+            step2()
+        el2 = timed_region(step2, sync_all, args.steps, engine, use_dist, device)
+        win2 = [el2 / args.steps * 1e3]
+        for _ in range(3):
+            win2.append(timed_region(step2, sync_all, args.steps, engine, use_dist, device) / args.steps * 1e3)
+        engine.set_status_mode("immediate")
+        # dopri5 takes the same number of evaluations per trajectory whichever rank integrates it (per-trajectory
+        # control), so the sharded batch's evaluation count is the weak problem's per-trajectory average x 256
+        evals2 = whole_job((nfe_fwd + nfe_aug) / B * B2 * N)
+        other = {"scaling": "strong", "trajectories_total": Bw, "trajectories_per_gpu": B2,
+                 "ms_per_step": el2 / args.steps * 1e3, "value": evals2 * args.steps / el2,
+                 "window_ms_per_step": win2,
+                 "note": "the ONE %d-trajectory batch of BASELINE.json config 4 sharded over the %d ranks, loss "
+                         "normalised by the global batch, grouped gradient all-reduce; evaluations counted from the "
+                         "per-trajectory NFE of the weak problem's trajectories (same distribution)" % (Bw, world)}
 
     if rank == 0:
         P = 4 * H * N + 2 * H + N
@@ -347,9 +481,12 @@ def main():
         # w.r.t. y + VJP w.r.t. the parameters).
         flop_fwd = (nfe_fwd / B) * 8.0 * B * N * H
         flop_adj = (nfe_aug / B) * 24.0 * B * N * H
+        mid = _lib.METHODS[wl["method"]]
         adj_kernel = {0: "k_solve_adj", 1: "k1_solve_adj", 2: "k1_solve_adj2", 3: "k1_solve_adj3"}[
-            _lib.load().phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS[wl["method"]])]
-        dom = adj_kernel if adj_ms_avg >= fwd_ms_avg else "k1_solve_fwd"   # key into the PMC summary
+            _lib.load().phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid)]
+        fwd_kernel = {0: "k_solve_fwd", 1: "k1_solve_fwd", 3: "k1_solve_fwd3"}[
+            _lib.load().phx_debug_forward_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid)]
+        dom = adj_kernel if adj_ms_avg >= fwd_ms_avg else fwd_kernel   # key into the PMC summary
         alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == adj_kernel else (alg_fwd, flop_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
         # Which roof binds: arithmetic intensity of the algorithmic figures against the fp32 ridge of the part
@@ -362,8 +499,8 @@ def main():
         # --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streams)
         # (the counters cannot be read while the bench runs un-profiled: the figure is the committed summary of the
         # profiled run of this same command, regenerated by tools/collect_profiles.sh)
-        traffic, pmc_file = None, None
-        for tag in ("r3", "r2"):
+        traffic, pmc_file, pmc_note = None, None, None
+        for tag in ("r4", "r3", "r2"):
             cand = os.path.join(ROOT, "profiles", "%s_%s_pmc_hbm.json" % (tag, args.workload))
             if os.path.exists(cand):
                 try:
@@ -371,8 +508,8 @@ def main():
                     traffic = (2.0 * pmc["FETCH_SIZE_KB_per_launch"][dom] + pmc["WRITE_SIZE_KB_per_launch"][dom]) * 1024.0
                     pmc_file = os.path.relpath(cand, ROOT)
                     break
-                except Exception:   # noqa: BLE001
-                    traffic = None
+                except Exception as exc:   # noqa: BLE001
+                    traffic, pmc_note = None, "%s: %r" % (os.path.basename(cand), exc)
         roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
                     "achieved": tflops if mfma_bound else achieved,
                     "peak": PEAK_MFMA_F32 if mfma_bound else PEAK_HBM,
@@ -385,20 +522,21 @@ def main():
                     "traffic": traffic,
                     "measured_hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
                     "traffic_source": ("%s (2*FETCH_SIZE + WRITE_SIZE of a separate profiled run of this command; not "
-                                       "measured in this run)" % pmc_file) if traffic else None,
+                                       "measured in this run)" % pmc_file) if traffic else pmc_note,
                     "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
-                    "forward": {"launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
+                    "forward": {"kernel": fwd_kernel, "launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
                                 "TFLOPs": flop_fwd / (fwd_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_fwd / B},
-                    "adjoint": {"launch_ms": adj_ms_avg, "GBps": alg_adj / (adj_ms_avg * 1e-3) / 1e9,
+                    "adjoint": {"kernel": adj_kernel, "launch_ms": adj_ms_avg, "GBps": alg_adj / (adj_ms_avg * 1e-3) / 1e9,
                                 "TFLOPs": flop_adj / (adj_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_aug / B}}
+        ws = sorted(windows)
         out = {
             "metric": "ODE-RHS evals/sec (genes x trajectories)", "value": value,
             "unit": "gene*trajectory RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": headline,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "genes": N, "hidden": H, "trajectories_per_gpu": B,
                        "method": wl["method"], "rtol": 1e-7, "atol": 1e-9, "time_points": wl["t"],
-                       "parallelism": "trajectory-sharded x%d, flat gradient all-reduce" % world,
+                       "parallelism": "trajectory-sharded x%d, grouped gradient all-reduce" % world,
                        "nfe_forward_per_step": nfe_fwd, "nfe_augmented_per_step": nfe_aug,
                        "status_readback": args.status},
             "roofline": roofline,
@@ -406,8 +544,16 @@ def main():
             # launch durations of the two solve kernels on this rank
             "rates": {"forward_evals_per_s": nfe_fwd * N / (fwd_ms_avg * 1e-3),
                       "augmented_evals_per_s": nfe_aug * N / (adj_ms_avg * 1e-3),
-                      "kernel_ms_per_step": fwd_ms_avg + adj_ms_avg},
+                      "kernel_ms_per_step": fwd_ms_avg + adj_ms_avg,
+                      "step_over_kernels": (elapsed / args.steps * 1e3) / (fwd_ms_avg + adj_ms_avg)},
+            "extra": {"step_windows_ms": {"windows": windows, "p50": float(np.percentile(windows, 50)),
+                                          "p90": float(np.percentile(windows, 90)), "min": ws[0], "max": ws[-1],
+                                          "note": "ms per step of six consecutive timed regions of `steps` steps each; the "
+                                                  "first is the one `value` and `ms_per_step` report"},
+                      "prewarm_steps": n_pre, "prewarm_windows_ms": [round(x, 4) for x in pre_windows]},
         }
+        if other is not None:
+            out["extra"]["strong"] = other
         if world == 1 and not args.no_extras:
             # informational: the reference's full training_step (train_insilico.py:124-140) with its K = 10 000-row
             # prior branch and an Adam step; NOT part of `value` (the metric counts ODE RHS evaluations only)
@@ -431,24 +577,25 @@ def main():
             # BASELINE.json config 4 is a STRONG-scaling problem (one 256-trajectory batch sharded 1/2/4/8): what one GPU
             # of such a run does per step (its shard of the batch, no all-reduce), measured here on this single device
             try:
-                if args.scaling == "weak" and not use_dist:
-                    from phoenix_amd import parallel
+                if headline == "weak" and not use_dist:
                     strong = {}
                     engine.set_status_mode(args.status)
-                    for W in (1, 2, 4, 8):
-                        lo, hi = parallel.shard_range(wl["B"], 0, W)
-                        ys, ts_, Gs = y0[lo:hi].contiguous(), t[lo:hi].contiguous(), G[:, lo:hi].contiguous()
-                        for _ in range(3):
-                            one_step(net, ys, ts_, Gs, wl["method"], 1)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for _ in range(20):
-                            one_step(net, ys, ts_, Gs, wl["method"], 1)
-                        engine.check_pending_status(wait=True)
-                        torch.cuda.synchronize()
-                        strong[str(W)] = (time.perf_counter() - t0) / 20 * 1e3
-                    engine.set_status_mode("immediate")
-                    # the same step with the library's default status mode (one blocking read at the end of backward())
+                    try:
+                        for W in (1, 2, 4, 8):
+                            lo, hi = parallel.shard_range(wl["B"], 0, W)
+                            ys, ts_, Gs = y0[lo:hi].contiguous(), t[lo:hi].contiguous(), G[:, lo:hi].contiguous()
+                            for _ in range(10):
+                                one_step(net, ys, ts_, Gs, wl["method"], 1)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(20):
+                                one_step(net, ys, ts_, Gs, wl["method"], 1)
+                            engine.check_pending_status(wait=True)
+                            torch.cuda.synchronize()
+                            strong[str(W)] = (time.perf_counter() - t0) / 20 * 1e3
+                    finally:
+                        engine.set_status_mode("immediate")
+                    # the same step with a blocking status read at the end of every backward()
                     for _ in range(3):
                         one_step(net, y0, t, G, wl["method"], 1)
                     torch.cuda.synchronize()
@@ -456,12 +603,13 @@ def main():
                     for _ in range(20):
                         one_step(net, y0, t, G, wl["method"], 1)
                     torch.cuda.synchronize()
-                    out["extra"] = {"strong_scaling_ms": strong,
-                                    "strong_scaling_note": "per-rank step time of a W-rank run of the SHARDED %d-trajectory "
-                                                           "batch (rank 0's shard, this one device, no all-reduce)" % wl["B"],
-                                    "ms_per_step_status_immediate": (time.perf_counter() - t0) / 20 * 1e3}
+                    out["extra"].update({
+                        "strong_scaling_ms": strong,
+                        "strong_scaling_note": "per-rank step time of a W-rank run of the SHARDED %d-trajectory "
+                                               "batch (rank 0's shard, this one device, no all-reduce)" % wl["B"],
+                        "ms_per_step_status_immediate": (time.perf_counter() - t0) / 20 * 1e3})
             except Exception as exc:   # noqa: BLE001
-                out["extra"] = {"error": repr(exc)[:200]}
+                out["extra"]["error"] = repr(exc)[:200]
         if world == 1 and not args.no_cpu_baseline:
             # both shapes BASELINE.md section 3 names; speed-ups are quoted against the stronger one
             loop = cpu_baseline(wl, net, y0, t, G)
@@ -485,9 +633,12 @@ _REAL_STDOUT = 1   # importing callers write the result line to fd 1; the script
 
 
 if __name__ == "__main__":
+    _args = parse_args()
+    if _args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(_args))         # nothing has touched a GPU yet
     # the contract is ONE JSON line on stdout: native libraries (RCCL prints a version banner at the first collective)
     # and anything else that writes to fd 1 go to stderr; the result line is written to the real stdout at the end
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    main()
+    main(_args)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 5
+#define PHX_ABI_VERSION 6
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -47,6 +47,9 @@ typedef struct phx_params {
 typedef struct phx_grads {
     float *Ws, *bs, *Wp, *bp, *WaT, *g;
     int overwrite;
+    float *Wa; /* optional (ABI 6): non-NULL = the gradient of net_alpha_combine.linear_out.weight is written HERE in the
+                  reference's own layout [N, 2H] (what autograd hands the optimizer, odenet.py:57-60) and WaT is not
+                  touched (may be NULL): the caller needs no transposed copy of the 2HN floats afterwards. */
 } phx_grads;
 
 /* torchdiffeq SOLVERS entries on the BASELINE path (odeint.py:14-27) */
@@ -96,6 +99,12 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T);
  * loop, an analysis scan) packs once.  phx_weight_image_bytes: buffer size (0: this shape has no MFMA plan). */
 size_t phx_weight_image_bytes(int N, int H);
 int phx_pack_weight_images(const phx_params *p, void *wimg, void *stream);
+/* ABI 6: the whole engine layout of one parameter version in ONE kernel, straight from the tensors the reference's
+ * ODENet holds (odenet.py:42-82): Ws, Wp [H, N], Wa = net_alpha_combine.linear_out.weight as PyTorch stores it [N, 2H],
+ * g [N].  Writes WaT_out [2H, N] (phx_params.WaT) and, when `wimg_out` is non-NULL (phx_weight_image_bytes(N, H) bytes),
+ * the packed weight images (phx_params.wimg).  Replaces a transposed copy + phx_pack_weight_images per optimizer step. */
+int phx_layout_params(const float *Ws, const float *Wp, const float *Wa, const float *g, int N, int H, float *WaT_out,
+                      void *wimg_out, void *stream);
 /* ... for phx_odeint with opts->calls = calls (0: this batch of calls cannot be planned, solve the calls one by one) */
 size_t phx_odeint_calls_workspace_bytes(int N, int H, int B, int T, int calls);
 
@@ -194,6 +203,9 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
  * a 16-vector private state).  bench.py keys its profile lookups with it.  The first form assumes dopri5. */
 int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control);
 int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int method);
+/* ... and which forward-solve kernel phx_odeint launches: 0 = k_solve_fwd (VALU), 1 = k1_solve_fwd (MFMA),
+ * 3 = k1_solve_fwd3 (MFMA, dopri5 with H <= 48). */
+int phx_debug_forward_kernel_m(int N, int H, int B, int T, int control, int method);
 
 #ifdef __cplusplus
 }

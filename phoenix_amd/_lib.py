@@ -16,7 +16,7 @@ class PhxParams(C.Structure):
 
 
 class PhxGrads(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("overwrite", C.c_int)]
+    _fields_ = [(k, C.c_void_p) for k in ("Ws", "bs", "Wp", "bp", "WaT", "g")] + [("overwrite", C.c_int), ("Wa", C.c_void_p)]
 
 
 class PhxSolveOpts(C.Structure):
@@ -28,7 +28,8 @@ EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_worksp
            "phx_rhs_vjp", "phx_odeint", "phx_odeint_adjoint_backward", "phx_debug_profile_region", "phx_debug_set_kernel_events",
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
            "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell",
-           "phx_debug_adjoint_kernel_m", "phx_prior_z_bytes", "phx_prior_mse_save", "phx_prior_vjp_saved")
+           "phx_debug_adjoint_kernel_m", "phx_prior_z_bytes", "phx_prior_mse_save", "phx_prior_vjp_saved",
+           "phx_layout_params", "phx_debug_forward_kernel_m")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -91,6 +92,8 @@ def load():
     lib.phx_weight_image_bytes.argtypes = [C.c_int, C.c_int]
     lib.phx_weight_image_bytes.restype = C.c_size_t
     lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
-    assert lib.phx_abi_version() == 5
+    lib.phx_layout_params.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+    lib.phx_debug_forward_kernel_m.argtypes = [C.c_int] * 6
+    assert lib.phx_abi_version() == 6
     _LIB = lib
     return lib

@@ -221,12 +221,9 @@ int adj2_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {
-            const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-            const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-            hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, npart, PP, p->N, p->H,
-                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
-                               (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
-            if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+            // later chunks of a large batch add
+            if (!launch_reduce_grads(w1.dtheta, npart, PP, p->N, p->H, grads, (grads->overwrite && b0 == 0) ? 1 : 0, st))
+                return PHX_ERR_LAUNCH;
         }
     }
     return PHX_OK;

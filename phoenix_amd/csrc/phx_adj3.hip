@@ -201,7 +201,7 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
             const long long total = (long long)d1.nblk * (4 * d1.HT * 2 * 64) + p->N + 2 * p->H;
             hipLaunchKernelGGL((k3_reduce_grads<3>), dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, w1.dtheta, npart, PP,
                                p->N, p->H, d1.nblk, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
-                               (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
+                               (grads->overwrite && b0 == 0) ? 1 : 0, grads->Wa);   // later chunks of a large batch add
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         }
     }

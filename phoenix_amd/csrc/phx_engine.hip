@@ -778,11 +778,7 @@ inline int grid_for(int work_items)
 
 inline int launch_reduce(const Dims &d, const WS &w, const phx_grads *g, hipStream_t st)
 {
-    const long long total = 4LL * d.H * d.N + d.N + 2 * d.H;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w.dtheta, d.GB, d.PP, d.N, d.H, g->Ws, g->Wp,
-                       g->WaT, g->g, g->bs, g->bp, g->overwrite);
-    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+    return launch_reduce_grads(w.dtheta, d.GB, d.PP, d.N, d.H, g, g->overwrite, st) ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
 
@@ -1078,11 +1074,7 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
                            pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc);
     }
     if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
-    const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
-                       grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
-    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+    return launch_reduce_grads(dth, pb.KS, PP, p->N, p->H, grads, grads->overwrite, st) ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
 // Full VJP of the RHS (or of prior_only_forward) on a batch: per hidden chunk A -> R per row chunk, E (input VJP, f, dg
@@ -1118,10 +1110,7 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
     }
     if (grads) {
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
-        const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, dth, pb.KS, PP, p->N, p->H, grads->Ws, grads->Wp,
-                           grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
+        if (!launch_reduce_grads(dth, pb.KS, PP, p->N, p->H, grads, grads->overwrite, st)) return PHX_ERR_LAUNCH;
         if (full)
             hipLaunchKernelGGL(k2_dg_finish, dim3((p->N + 255) / 256), dim3(256), 0, st, dgp, pb.d.TG * 4, p->N, p->g,
                                grads->g);
@@ -1243,7 +1232,7 @@ int phx_prior_vjp_saved(const phx_params *p, const float *X, const float *cot, c
                         int B, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (bad_params(p) || !X || !cot || !z_saved || !grads || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
-    if (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g) return PHX_ERR_BAD_ARG;
+    if (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || (!grads->WaT && !grads->Wa) || !grads->g) return PHX_ERR_BAD_ARG;
     PlanBatch pb;
     if (!plan_batch(p->N, p->H, B, &pb) || pb.d.HC != 1) return PHX_ERR_BAD_ARG;
     if (workspace_bytes < pb.total) return PHX_ERR_WORKSPACE;
@@ -1322,6 +1311,12 @@ int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int meth
     return pick_chunk_v1(N, H, B, T, control, true) > 0 ? 1 : 0;
 }
 
+int phx_debug_forward_kernel_m(int N, int H, int B, int T, int control, int method)
+{
+    if (fwd3_chunk(N, H, B, T, control, method) > 0) return 3;
+    return pick_chunk_v1(N, H, B, T, control, false) > 0 ? 1 : 0;
+}
+
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
 {
     if (N <= 0 || H <= 0 || B <= 0 || T < 0) return 0;
@@ -1375,6 +1370,17 @@ int phx_pack_weight_images(const phx_params *p, void *wimg, void *stream)
     const int HC = (p->H + 127) / 128, Hc = (p->H + HC - 1) / HC, HT = solve_ht(HC, Hc);
     hipLaunchKernelGGL(k1_pack_images, dim3(((p->N + 31) / 32) * HC), dim3(256), 0, (hipStream_t)stream, to_net(p),
                        (float *)wimg, HT, HC, Hc, blk_floats_ch(HT, Hc));
+    return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+}
+
+int phx_layout_params(const float *Ws, const float *Wp, const float *Wa, const float *g, int N, int H, float *WaT_out,
+                      void *wimg_out, void *stream)
+{
+    if (!Ws || !Wp || !Wa || !g || !WaT_out || N <= 0 || H <= 0) return PHX_ERR_BAD_ARG;
+    if (wimg_out && phx_weight_image_bytes(N, H) == 0) return PHX_ERR_BAD_ARG;
+    const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC, HT = solve_ht(HC, Hc);
+    hipLaunchKernelGGL(k1_layout_params, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, Ws, Wp, Wa, g, N, H,
+                       WaT_out, (float *)wimg_out, HT, HC, Hc, blk_floats_ch(HT, Hc));
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
@@ -1444,7 +1450,7 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
                 float *f_out, int B, int prior_only, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (bad_params(p) || !y || !cot || B <= 0 || !workspace) return PHX_ERR_BAD_ARG;
-    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
+    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || (!grads->WaT && !grads->Wa) || !grads->g))
         return PHX_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (prior_only && grads && !vjp_y && !f_out) {   // the prior branch's backward: MFMA parameter gradients
@@ -1485,11 +1491,8 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
                                    pe.npass, PP);
             }
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
-            const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-            const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-            hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta, pe.d.TG * pe.d.NW, PP, p->N, p->H,
-                               grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp, grads->overwrite);
-            return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
+            return launch_reduce_grads(w1.dtheta, pe.d.TG * pe.d.NW, PP, p->N, p->H, grads, grads->overwrite, st)
+                       ? PHX_OK : PHX_ERR_LAUNCH;
         }
     }
     {   // everything else (dL/dy wanted, f wanted, or the full RHS): MFMA kernel chain A -> R -> E (+ C), one pass per
@@ -1623,7 +1626,7 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
     if (bad_params(p) || !t_all || !o || !y_saved_all || !grad_y_all || !adj_y0_all || !status_all || !nfe_all ||
         !nsteps_all || B <= 0 || T < 1 || !workspace)
         return PHX_ERR_BAD_ARG;
-    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || !grads->WaT || !grads->g))
+    if (grads && (!grads->Ws || !grads->bs || !grads->Wp || !grads->bp || (!grads->WaT && !grads->Wa) || !grads->g))
         return PHX_ERR_BAD_ARG;
     if (o->method < PHX_EULER || o->method > PHX_DOPRI5) return PHX_ERR_BAD_ARG;
     if (o->control == PHX_CTRL_SHARED && o->t_per_sample) return PHX_ERR_BAD_ARG;
@@ -1690,14 +1693,11 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
             ev_end(st);
             if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
             if (grads) {
-                const long long total = 4LL * p->H * p->N + p->N + 2 * p->H;
-                const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-                hipLaunchKernelGGL(k_reduce_grads, dim3(blocks), dim3(256), 0, st, w1.dtheta,
-                                   /* partials of waves that own tiles (helper waves of a single small group write none) */
-                                   d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW, PP, p->N,
-                                   p->H, grads->Ws, grads->Wp, grads->WaT, grads->g, grads->bs, grads->bp,
-                                   (grads->overwrite && b0 == 0) ? 1 : 0);   // later chunks of a large batch add
-                if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+                // partials of waves that own tiles (helper waves of a single small group write none); later chunks of a
+                // large batch add
+                if (!launch_reduce_grads(w1.dtheta, d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW, PP, p->N,
+                                         p->H, grads, (grads->overwrite && b0 == 0) ? 1 : 0, st))
+                    return PHX_ERR_LAUNCH;
             }
         }
     }

@@ -68,18 +68,19 @@ class Params:
         self.bs = bs.detach().contiguous()
         self.Wp = Wp.detach().contiguous()
         self.bp = bp.detach().contiguous()
-        self.WaT = Wa.detach().t().contiguous()   # gene-contiguous [2H, N]
         self.g = g.detach().reshape(-1).contiguous()
         self.device = Ws.device
-        self.c = _lib.PhxParams(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g),
-                                self.N, self.H, None)
-        # LDS weight images of these values, packed once here instead of once per solve launch (phx_params.wimg)
-        self.wimg = None
+        # The engine layout of this parameter version in ONE kernel (phx_layout_params, ABI 6), straight from
+        # net_alpha_combine.linear_out.weight as PyTorch stores it ([N, 2H]): the gene-contiguous transpose WaT [2H, N]
+        # and the packed LDS weight images (phx_params.wimg) that the forward and the backward solve of a step share.
+        wa = Wa.detach().contiguous()
+        self.WaT = torch.empty((2 * self.H, self.N), dtype=torch.float32, device=self.device)
         nbytes = _lib.load().phx_weight_image_bytes(self.N, self.H)
-        if nbytes:
-            self.wimg = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            _check_call(_lib.load().phx_pack_weight_images(C.byref(self.c), _p(self.wimg), _stream_ptr()))
-            self.c.wimg = self.wimg.data_ptr()
+        self.wimg = torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes else None
+        _check_call(_lib.load().phx_layout_params(_p(self.Ws), _p(self.Wp), _p(wa), _p(self.g), self.N, self.H,
+                                                  _p(self.WaT), _p(self.wimg), _stream_ptr()))
+        self.c = _lib.PhxParams(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g),
+                                self.N, self.H, self.wimg.data_ptr() if nbytes else None)
         # ready event, unconditionally: the contiguous / transposed copies above are written on this stream too
         self._ready_stream = torch.cuda.current_stream()
         self._ready_event = torch.cuda.Event()
@@ -127,8 +128,9 @@ def invalidate_params():
 
 
 class Grads:
-    """One flat buffer carved into the six gradient tensors.  It is NOT zero-filled: the engine call it is handed to
-    writes every element (`phx_grads.overwrite`)."""
+    """One flat buffer carved into the six gradient tensors, every one in the REFERENCE's layout (dWa as [N, 2H],
+    phx_grads.Wa): what the engine writes is what autograd hands the optimizer, no transposed copy in between.  It is
+    NOT zero-filled: the engine call it is handed to writes every element (`phx_grads.overwrite`)."""
 
     def __init__(self, p):
         H, N = p.H, p.N
@@ -136,12 +138,12 @@ class Grads:
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=p.device)
         parts = torch.split(self.flat, sizes)
         self.Ws, self.bs, self.Wp, self.bp = parts[0].view(H, N), parts[1], parts[2].view(H, N), parts[3]
-        self.WaT, self.g = parts[4].view(2 * H, N), parts[5]
-        self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), _p(self.WaT), _p(self.g), 1)
+        self.Wa, self.g = parts[4].view(N, 2 * H), parts[5]
+        self.c = _lib.PhxGrads(_p(self.Ws), _p(self.bs), _p(self.Wp), _p(self.bp), None, _p(self.g), 1, _p(self.Wa))
 
     def as_reference_layout(self, g_shape):
         """(Ws, bs, Wp, bp, Wa[N,2H], g[1,N]) gradients in the reference's parameter layouts"""
-        return self.Ws, self.bs, self.Wp, self.bp, self.WaT.t(), self.g.reshape(g_shape)
+        return self.Ws, self.bs, self.Wp, self.bp, self.Wa, self.g.reshape(g_shape)
 
 
 def _check_call(rc):
@@ -225,6 +227,7 @@ def rhs_forward(p, y, prior_only=False):
     y2 = y.detach().reshape(-1, p.N).contiguous()
     out = torch.empty_like(y2)
     B = y2.shape[0]
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_RHS_FORWARD, p.N, p.H, B, 0, y.device)
     _check_call(_lib.load().phx_rhs_forward(C.byref(p.c), _p(y2), _p(out), B, int(prior_only), _p(ws), nb,
                                             _stream_ptr()))
@@ -241,6 +244,7 @@ def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True, f_out
     B = y2.shape[0]
     vjp = torch.empty_like(y2) if want_vjp_y else None
     grads = p.new_grads() if want_grads else None
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_RHS_VJP, p.N, p.H, B, 0, y.device)
     if f_out is not None:
         _require_gpu(f_out, "f_out")
@@ -269,6 +273,7 @@ def prior_mse(p, X, target, keep_hidden=False):
         return None
     cot = torch.empty_like(x2)
     loss = torch.empty(1, dtype=torch.float32, device=x2.device)
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_RHS_FORWARD, p.N, p.H, B, 0, X.device)
     zbytes = _lib.load().phx_prior_z_bytes(p.N, p.H, B) if keep_hidden else 0
     if zbytes:
@@ -293,7 +298,14 @@ def prior_vjp_saved(p, X, cot, z):
     x2 = X.detach().reshape(-1, p.N).contiguous()
     c2 = cot.detach().reshape(-1, p.N).contiguous()
     B = x2.shape[0]
+    # `z` must be the buffer prior_mse(keep_hidden=True) filled for THIS batch size: the kernels index it by tile
+    zbytes = _lib.load().phx_prior_z_bytes(p.N, p.H, B)
+    if (z is None or not z.is_cuda or z.dtype != torch.float32 or not z.is_contiguous() or zbytes == 0 or
+            z.numel() * 4 != zbytes):
+        raise ValueError("prior_vjp_saved: `z` is not the hidden-row buffer of prior_mse(keep_hidden=True) for a batch "
+                         "of %d rows (N=%d, H=%d)" % (B, p.N, p.H))
     grads = p.new_grads()
+    p.on_current_stream()
     ws, nb = _workspace(_lib.OP_RHS_VJP, p.N, p.H, B, 0, X.device)
     _check_call(_lib.load().phx_prior_vjp_saved(C.byref(p.c), _p(x2), _p(c2), _p(z), C.byref(grads.c), B, _p(ws), nb,
                                                 _stream_ptr()))

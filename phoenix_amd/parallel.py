@@ -48,6 +48,16 @@ def allreduce_grads(module, scale=None, extra=()):
         torch._foreach_mul_(grads, scale)
 
 
+def zero_grads_where_failed(module, flag):
+    """device-side guard of the deferred mode: where the summed failure flag is non-zero every gradient becomes 0 (no
+    host round trip).  A select, not a multiply: the engine writes NaN into outputs a failed solve never reached, so the
+    summed gradients of a failed step may hold NaN / Inf, and 0 * NaN is NaN."""
+    ok = flag.reshape(()) == 0
+    for p in module.parameters():
+        if p.requires_grad and p.grad is not None:
+            p.grad.copy_(torch.where(ok, p.grad, torch.zeros((), dtype=p.grad.dtype, device=p.grad.device)))
+
+
 class GradSync:
     """`grad_sync` of `training_step` for data-parallel runs: the gradient all-reduce, plus agreement on failure.
 
@@ -59,8 +69,9 @@ class GradSync:
     memory like the deferred solver status (phoenix_amd.engine.set_status_mode) and costs no host synchronisation.
 
     Deferred mode and the optimizer step: the healthy ranks learn of the failure one call late, i.e. AFTER their
-    `opt.step()` of the failed step.  So that they do not apply the incomplete sum, the reduced gradients are multiplied
-    by `flag == 0` on the device (no host round trip): on a failed step every rank steps with all-zero gradients.  A
+    `opt.step()` of the failed step.  So that they do not apply the incomplete sum, the reduced gradients are replaced
+    by zeros where `flag != 0` on the device (`torch.where`: no host round trip, and non-finite sums do not survive as
+    0 * NaN would): on a failed step every rank steps with all-zero gradients.  A
     stateless optimizer then changes nothing; one with momentum (Adam) still moves the parameters by its running
     averages on the healthy ranks while the failing rank does not step at all -- after this error the replicas must be
     restored from the last checkpoint on ALL ranks before training continues."""
@@ -94,9 +105,7 @@ class GradSync:
             if float(flag[0]) > 0:
                 raise RuntimeError("phoenix_amd: a solve failed on another rank")
             return
-        ps = [p.grad for p in module.parameters() if p.requires_grad and p.grad is not None]
-        if ps:
-            torch._foreach_mul_(ps, (flag == 0).to(flag.dtype))     # a failed step updates with zero gradients
+        zero_grads_where_failed(module, flag)
         host = torch.empty(1, dtype=torch.float32, pin_memory=True)
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.phx_abi_version() == 5
+    assert lib.phx_abi_version() == 6
     assert lib.phx_status_string(2).decode() == "underflow in dt"
 
 
@@ -41,6 +41,7 @@ def test_null_arguments_are_rejected_without_a_gpu():
     lib = _lib.load()
     assert lib.phx_rhs_forward(None, None, None, 1, 0, None, 0, None) == 4  # PHX_ERR_BAD_ARG
     assert lib.phx_pack_weight_images(None, None, None) == 4
+    assert lib.phx_layout_params(None, None, None, None, 1, 1, None, None, None) == 4
     assert lib.phx_prior_targets_sell(None, None, None, None, None, None, 1, 1, None) == 4
     # weight images: a pure function of (N, H); 0 where no MFMA plan exists
     a, b = lib.phx_weight_image_bytes(350, 40), lib.phx_weight_image_bytes(11165, 40)

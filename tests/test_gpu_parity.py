@@ -324,7 +324,7 @@ def test_rhs_vjp_kernel_chain_vs_oracle_rows_and_valu_engine(pa, dev, oracle, mo
     vjp0, grads0 = engine.rhs_vjp(P, y, cot, prior_only=prior_only)
     monkeypatch.delenv("PHX_ENGINE")
     assert relerr(vjp.cpu().numpy(), vjp0.cpu().numpy()) < TOL_RHS
-    for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+    for k in ("Ws", "bs", "Wp", "bp", "Wa", "g"):
         a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
         assert relerr(a, b) < 2 * TOL_RHS or (np.abs(b).max() == 0 and np.abs(a).max() == 0), k
     # f(y) from the same chain (the C entry point's f_out) equals the forward entry point
@@ -821,6 +821,56 @@ def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant
         assert relerr(gg[k], gr_ref[k]) < gtol, k
 
 
+@pytest.mark.parametrize("B", [64, 200])
+def test_step_counts_of_the_third_generation_kernels_match_the_first(pa, dev, oracle, monkeypatch, B):
+    """Canary for the wrong-step-size signature of DESIGN.md section 2 ("one signature"): sibling instantiations of the
+    third-generation kernels took the maximal growth factor on lanes {12-15, 28-31, 44-47, 60-63} of the controller wave
+    (as if error_ratio were 0) when a group had more than 64 gene tiles; results stayed plausible and no status was set.
+    phx_fwd3.hip / phx_adj3.hip are therefore built without IPRA (phoenix_amd/build.py: UNIT_FLAGS).  This test names a
+    recurrence: multi-step per-trajectory dopri5 solves on shapes whose groups have MORE than 64 gene tiles (N = 11 165:
+    175 tiles at B = 64, 88 at B = 200) must take the same number of steps per trajectory through k1_solve_fwd3 /
+    k1_solve_adj3 as through the first-generation kernels (accept/reject noise aside), with no lane class standing
+    out, and sampled rows must agree with the oracle."""
+    from phoenix_amd import _lib, engine
+    N, H = 11165, 40
+    p = rand_params(N, H, seed=41, std=0.05)
+    net = make_net(pa, dev, p)
+    r = np.random.RandomState(3)
+    y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
+    t = np.stack([np.array([0.0, 0.25 + 0.01 * (b % 16)]) for b in range(B)]).astype(np.float32)
+    G = (r.randn(B, 2, N) / (B * N)).astype(np.float32)
+    G[:, 0] = 0
+    pe = engine.params_cached(*pa.odenet.params_of(net))
+    y0d, td = torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev).contiguous()
+    Gd = torch.from_numpy(np.ascontiguousarray(G.transpose(1, 0, 2))).to(dev)
+    assert _lib.load().phx_debug_adjoint_kernel_m(N, H, B, 2, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS["dopri5"]) == 3
+
+    def run():
+        sol, st, nfe, ns = engine.solve_forward(pe, y0d, td, "dopri5", _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, 2)
+        adj, gr, st2, nfe2, ns2 = engine.solve_adjoint(pe, td, sol, Gd, "dopri5", _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9,
+                                                       True, 2)
+        assert int(st.max()) == 0 and int(st2.max()) == 0
+        return sol.cpu().numpy(), ns.cpu().numpy(), adj.cpu().numpy(), ns2.cpu().numpy(), gr.flat.cpu().numpy()
+
+    sol3, nsf3, adj3, nsb3, gr3 = run()
+    monkeypatch.setenv("PHX_FWD", "v1")
+    monkeypatch.setenv("PHX_ADJ", "v1")
+    sol1, nsf1, adj1, nsb1, gr1 = run()
+    monkeypatch.delenv("PHX_FWD")
+    monkeypatch.delenv("PHX_ADJ")
+    assert nsf1.min() >= 3 and nsb1.min() >= 3, "the canary needs multi-step solves"
+    for name, a, b in (("forward", nsf3, nsf1), ("backward", nsb3, nsb1)):
+        assert np.abs(a.astype(np.int64) - b).max() <= 2, (name, a.tolist(), b.tolist())
+        lanes = np.arange(B) % 16
+        bad, good = a[lanes >= 12], a[lanes < 12]
+        assert abs(bad.mean() - good.mean()) <= 1.0, (name, "trajectories 12-15 of the tiles step differently", a.tolist())
+    assert relerr(sol3, sol1) < TOL_DOPRI and relerr(adj3, adj1) < TOL_DOPRI_GRAD and relerr(gr3, gr1) < TOL_DOPRI_GRAD
+    onet = onet_of(oracle, p)
+    rows = [12, 13, 15, 28, 47, 63, 5][:7] if B >= 64 else list(range(B))
+    ref = oracle.odeint_per_sample(onet, y0[rows], t[rows], method="dopri5")
+    assert relerr(sol3.transpose(1, 0, 2)[rows], ref) < TOL_DOPRI
+
+
 @pytest.mark.parametrize("N,H,B,adj", [(300, 10, 5, None), (300, 10, 5, "v3"), (1500, 12, 20, None), (1500, 12, 37, "v1")])
 def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle, monkeypatch, N, H, B, adj):
     """odeint_adjoint on a batched y0 with ONE controller (reference semantics) over several output times:
@@ -927,7 +977,7 @@ def test_prior_backward_from_saved_hidden_rows_equals_recomputation(pa, dev, N, 
     _, g0 = engine.rhs_vjp(P, X, cot0, True, want_grads=True, want_vjp_y=False)
     if z is not None:
         g1 = engine.prior_vjp_saved(P, X, cot1, z)
-        for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+        for k in ("Ws", "bs", "Wp", "bp", "Wa", "g"):
             assert torch.equal(getattr(g0, k), getattr(g1, k)), k
 
 
@@ -1228,7 +1278,7 @@ def test_random_shapes_new_paths_agree_with_their_references(pa, dev, monkeypatc
         vjp0, grads0 = engine.rhs_vjp(P, y, cot, prior_only=po)
         monkeypatch.delenv("PHX_ENGINE")
         assert relerr(vjp.cpu().numpy(), vjp0.cpu().numpy()) < TOL_RHS, (N, H, Bv, po)
-        for k in ("Ws", "bs", "Wp", "bp", "WaT", "g"):
+        for k in ("Ws", "bs", "Wp", "bp", "Wa", "g"):
             a, b = getattr(grads, k).cpu().numpy(), getattr(grads0, k).cpu().numpy()
             assert (np.abs(b).max() == 0 and np.abs(a).max() == 0) or relerr(a, b) < 2 * TOL_RHS, (k, N, H, Bv, po)
 

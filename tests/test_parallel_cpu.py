@@ -201,6 +201,50 @@ def test_a_failed_solve_on_one_rank_stops_every_rank_in_the_same_step():
     assert res[0][0] == "ok" and len(res[0]) == 2 and res[0][1].startswith("RuntimeError") and "another rank" in res[0][1]
 
 
+def _nan_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phoenix_amd import parallel
+    out = []
+    for failing_step in (True, False):
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(4, 2)
+        lin(torch.ones(3, 4)).sum().backward()
+        if failing_step and rank == 1:      # what a failed solve leaves behind: NaN where it never got to
+            lin.weight.grad[0, 0] = float("nan")
+            lin.bias.grad[1] = float("inf")
+        flag = torch.full((1,), 1.0 if (failing_step and rank == 1) else 0.0)
+        parallel.allreduce_grads(lin, extra=[flag])
+        parallel.zero_grads_where_failed(lin, flag)
+        out.append((float(flag[0]), lin.weight.grad.reshape(-1).tolist(), lin.bias.grad.tolist()))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_guard_zeroes_non_finite_gradients_of_a_failed_step():
+    """the device-side guard GradSync applies in deferred mode: a failed step (flag summed over the ranks != 0) leaves
+    all-zero gradients on EVERY rank even where the failing rank contributed NaN / Inf (0 * NaN would stay NaN); a
+    healthy step keeps the reduced gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        (f1, w1, b1), (f0, w0, b0) = res[rank]
+        assert f1 == 1.0 and all(v == 0.0 for v in w1 + b1)
+        assert f0 == 0.0 and all(v == 6.0 for v in w0) and all(v == 6.0 for v in b0)   # 3 rows of ones x 2 ranks
+
+
 def test_shard_range_covers_everything():
     from phoenix_amd.parallel import shard_range
     for n in (1, 7, 256, 1023):

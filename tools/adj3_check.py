@@ -85,7 +85,7 @@ def case(name, N, H, B, tgrid, std, seed=0, gscale=1.0, with_oracle=True):
                                                       theta_in_norm=False)
         HN = H * N
         flat = g3.cpu().numpy()
-        got = {"Ws": flat[:HN].reshape(H, N), "Wp": flat[HN + H:2 * HN + H].reshape(H, N)}   # Ws | bs | Wp | bp | WaT | g
+        got = {"Ws": flat[:HN].reshape(H, N), "Wp": flat[HN + H:2 * HN + H].reshape(H, N)}   # Ws | bs | Wp | bp | Wa | g
         msg += "  v3-oracle: adj_y0 %.2e Ws %.2e Wp %.2e" % (relerr(a3.cpu().numpy(), adj_ref), relerr(got["Ws"], gr["Ws"]),
                                                            relerr(got["Wp"], gr["Wp"]))
     print(msg, flush=True)
