@@ -1379,7 +1379,7 @@ int phx_layout_params(const float *Ws, const float *Wp, const float *Wa, const f
     if (!Ws || !Wp || !Wa || !g || !WaT_out || N <= 0 || H <= 0) return PHX_ERR_BAD_ARG;
     if (wimg_out && phx_weight_image_bytes(N, H) == 0) return PHX_ERR_BAD_ARG;
     const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC, HT = solve_ht(HC, Hc);
-    hipLaunchKernelGGL(k1_layout_params, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, Ws, Wp, Wa, g, N, H,
+    hipLaunchKernelGGL(k1_layout_params, dim3((N + 31) / 32, 2 + (2 * H + 63) / 64), dim3(256), 0, (hipStream_t)stream, Ws, Wp, Wa, g, N, H,
                        WaT_out, (float *)wimg_out, HT, HC, Hc, blk_floats_ch(HT, Hc));
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }

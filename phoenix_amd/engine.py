@@ -328,8 +328,8 @@ def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f3
         raise ValueError("calls > 1 needs shared step control and B divisible by calls")
     T = t64.shape[-1]
     sol = torch.empty((T, B, N), dtype=torch.float32, device=y0.device)
-    if stats is None:
-        stats = torch.zeros((3, B), dtype=torch.int32, device=y0.device)
+    if stats is None:      # not zero-filled: every solve kernel writes status / nfe / nsteps of every trajectory
+        stats = torch.empty((3, B), dtype=torch.int32, device=y0.device)
     p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device, calls)
     o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls)
@@ -340,11 +340,11 @@ def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f3
 
 def solve_adjoint(p, t64, y_saved, grad_y, method, control, rtol, atol, t_per_sample, t_is_f32, want_grads=True,
                   max_num_steps=0, stats=None):
-    """y_saved, grad_y [T,B,N] -> adj_y0 [B,N], Grads, status, nfe, nsteps.  `stats`: a zeroed int32 [3,B] to use."""
+    """y_saved, grad_y [T,B,N] -> adj_y0 [B,N], Grads, status, nfe, nsteps.  `stats`: an int32 [3,B] to use (rows contiguous)."""
     T, B, N = y_saved.shape
     adj = torch.empty((B, N), dtype=torch.float32, device=y_saved.device)
     if stats is None:
-        stats = torch.zeros((3, B), dtype=torch.int32, device=y_saved.device)
+        stats = torch.empty((3, B), dtype=torch.int32, device=y_saved.device)
     grads = p.new_grads() if want_grads else None
     p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ADJOINT, p.N, p.H, B, T, y_saved.device)

