@@ -188,13 +188,21 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         else
             hipLaunchKernelGGL(k1_pack_images, dim3(d1.nblk), dim3(256), 0, st, to_net(p), (float *)w1.wimg, d1.HT, 1, p->H,
                                blk_floats_ch(d1.HT, p->H));
-        const void *fn = reinterpret_cast<const void *>(k1_solve_adj3<3>);
+        // HALF: the last hidden tile has at most 8 live rows (H <= 40 with three tiles; rho16 in phx_mfma_v3common.inc)
+        const char *eh = getenv("PHX_V3_HALF");   // diagnostic: 0 = full last tile also where half of it is padding
+        const bool half = p->H <= 16 * (d1.HT - 1) + 8 && !(eh && eh[0] == '0');
+        const void *fn = half ? reinterpret_cast<const void *>(k1_solve_adj3<3, true>)
+                              : reinterpret_cast<const void *>(k1_solve_adj3<3, false>);
         if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
         // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
         if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
         ev_begin(st);
-        hipLaunchKernelGGL((k1_solve_adj3<3>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y, adj_y0,
-                           status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
+        if (half)
+            hipLaunchKernelGGL((k1_solve_adj3<3, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
+                               adj_y0, status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
+        else
+            hipLaunchKernelGGL((k1_solve_adj3<3, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
+                               adj_y0, status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
         ev_end(st);
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {

@@ -182,7 +182,10 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
             ev_end(st);
             return PHX_OK;
         };
-        const int lrc = launch(k1_solve_fwd3<3, 256>);
+        // HALF: the last hidden tile has at most 8 live rows (H <= 40 with three tiles; rho16 in phx_mfma_v3common.inc)
+        const char *eh = getenv("PHX_V3_HALF");   // diagnostic: 0 = full last tile also where half of it is padding
+        const bool half = p->H <= 16 * (d1.HT - 1) + 8 && !(eh && eh[0] == '0');
+        const int lrc = half ? launch(k1_solve_fwd3<3, 256, true>) : launch(k1_solve_fwd3<3, 256, false>);
         if (lrc != PHX_OK) return lrc;
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     }

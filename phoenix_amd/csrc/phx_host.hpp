@@ -82,10 +82,10 @@ inline bool set_lds_resident(K kernel, size_t bytes, int threads, int grid)
 
 // diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
 inline thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-inline void ev_begin(hipStream_t st) { if (g_ev_start) hipEventRecord(g_ev_start, st); }
+inline void ev_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }
 inline void ev_end(hipStream_t st)
 {
-    if (g_ev_stop) hipEventRecord(g_ev_stop, st);
+    if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
     g_ev_start = nullptr;
     g_ev_stop = nullptr;
 }
