@@ -117,6 +117,41 @@ __device__ __forceinline__ void act_pair_fast(float y, float &a, float &l)
     l = fast_log1p(a);
 }
 
+// act_pair_fast on 2 NP values, written on element PAIRS so that the subtractions, the Newton step of the reciprocal
+// and the 13-term log1p series issue as v_pk_add / v_pk_mul / v_pk_fma_f32 (one instruction per pair; the same operations
+// in the same order per element, and v_pk_fma_f32 rounds like v_fma_f32 on this part: tools/membench/pk_fma_bits.hip).
+// Only |s|, the two transcendentals and the final select stay per element: ~15 instead of ~26 vector instructions per value.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <int NP>
+__device__ __forceinline__ void act_pair_fast_pk(const float *y, float *a, float *l)
+{
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const f32x2 yv = {y[2 * p], y[2 * p + 1]};
+        const f32x2 s = yv - (f32x2){0.5f, 0.5f};
+        const f32x2 d = (f32x2){1.0f, 1.0f} + (f32x2){fabsf(s.x), fabsf(s.y)};
+        f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        r = pk_fma(pk_fma(-d, r, (f32x2){1.0f, 1.0f}), r, r);                 // fast_rcp: one Newton step
+        const f32x2 av = s * r;
+        const f32x2 x = -av;
+        f32x2 sm = {1.0f / 13.0f, 1.0f / 13.0f};
+#define PHX_H(c) sm = pk_fma(sm, x, (f32x2){c, c})
+        PHX_H(1.0f / 12.0f); PHX_H(1.0f / 11.0f); PHX_H(1.0f / 10.0f); PHX_H(1.0f / 9.0f); PHX_H(1.0f / 8.0f);
+        PHX_H(1.0f / 7.0f);  PHX_H(1.0f / 6.0f);  PHX_H(1.0f / 5.0f);  PHX_H(1.0f / 4.0f); PHX_H(1.0f / 3.0f);
+        PHX_H(0.5f);         PHX_H(1.0f);
+#undef PHX_H
+        const f32x2 small = av * sm;
+        const f32x2 one_a = (f32x2){1.0f, 1.0f} + av;
+        const f32x2 big = (f32x2){__builtin_amdgcn_logf(one_a.x), __builtin_amdgcn_logf(one_a.y)} *
+                          (f32x2){0.69314718055994531f, 0.69314718055994531f};
+        a[2 * p] = av.x; a[2 * p + 1] = av.y;
+        l[2 * p] = (fabsf(av.x) < 0.25f) ? small.x : big.x;
+        l[2 * p + 1] = (fabsf(av.y) < 0.25f) ? small.y : big.y;
+    }
+}
+__device__ __forceinline__ void act_pair_fast8(const float (&y)[8], float (&a)[8], float (&l)[8]) { act_pair_fast_pk<4>(y, a, l); }
+
 // closed-form derivatives
 __device__ __forceinline__ void act_grad(float y, float &da, float &dl)
 {

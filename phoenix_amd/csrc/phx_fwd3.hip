@@ -35,11 +35,10 @@ bool plan_fwd3(int N, int H, int B, int T, int control, int method, D1 *out)
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     long long best_cost = -1;
     D1 best{};
-    // One wave per SIMD (NW <= 4).  The eight-wave form (two waves per SIMD under a 256-register cap) computed wrong
-    // step sizes for the trajectories 12..15 of the tiles 4..7 of a group as soon as a group had more than 64 gene tiles
-    // (tools/fwd3_check.py; not the private segment, not the out-of-line controller math: DESIGN.md section 2, "one
-    // signature") -- not understood, so that form is not built.  Four waves are faster than k1_solve_fwd's eight at C4
-    // anyway (0.26 vs 0.29 ms).
+    // One wave per SIMD (NW <= 4).  The eight-wave form (two waves per SIMD under a 256-register cap) computed wrong step
+    // sizes in round 3 -- the store-data hazard of phx_mfma_v3common.inc, not the form itself: rebuilt in round 4 with the
+    // guarded stores it passes the parity suite, and it is no faster at C4 (0.266-0.268 ms against 0.268-0.270: 38-148
+    // spilled registers, twice the exchange members per group), so it is not built.
     int nwmax = 4;
     if (const char *e = getenv("PHX_V1_MAXNW")) nwmax = std::min(nwmax, std::max(1, atoi(e)));
     for (int NW = nwmax; NW >= 1; NW >>= 1)
