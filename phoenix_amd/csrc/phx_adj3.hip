@@ -49,7 +49,8 @@ bool plan_adj3(int N, int H, int B, int T, int control, int method, D1 *out)
             const size_t cb = ctl3_bytes(Bt, ntg);
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
-            for (int NB = 1; NB <= NBmax; ++NB) {
+            const char *enb = getenv("PHX_V3_NB");   // experiment: smallest gene tile to consider
+            for (int NB = enb ? std::max(1, atoi(enb)) : 1; NB <= NBmax; ++NB) {
                 const int G = (nblk + NB - 1) / NB;
                 if ((long long)TG * G > cus) continue;
                 const long long cost = (long long)TPW * NB * 1000 + Bt / 4 - (helpers && TPW == 1 ? 50 : 0);
@@ -197,14 +198,10 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
         if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
         ev_begin(st);
-        if (half)
-            hipLaunchKernelGGL((k1_solve_adj3<3, true>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
-        else
-            hipLaunchKernelGGL((k1_solve_adj3<3, false>), grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y,
-                               adj_y0, status, nfe, nsteps, (grads ? 1 : 0) | prof_flags, PP);
+        const hipError_t lerr = launch_persistent(fn, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y, adj_y0,
+                                                  status, nfe, nsteps, (int)((grads ? 1 : 0) | prof_flags), PP);
         ev_end(st);
-        if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
+        if (lerr != hipSuccess || hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {
             const long long total = (long long)d1.nblk * (4 * d1.HT * 2 * 64) + p->N + 2 * p->H;
             hipLaunchKernelGGL((k3_reduce_grads<3>), dim3((unsigned int)((total + 255) / 256)), dim3(256), 0, st, w1.dtheta, npart, PP,

@@ -50,7 +50,8 @@ bool plan_fwd3(int N, int H, int B, int T, int control, int method, D1 *out)
             const size_t cb = ctlf3_bytes(Bt, ntg);
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
-            for (int NB = 1; NB <= NBmax; ++NB) {
+            const char *enb = getenv("PHX_V3_NB");   // experiment: smallest gene tile to consider
+            for (int NB = enb ? std::max(1, atoi(enb)) : 1; NB <= NBmax; ++NB) {
                 const int G = (nblk + NB - 1) / NB;
                 if ((long long)TG * G > cus) continue;
                 const long long cost = (long long)TPW * NB * ((NW + 3) / 4) * 1000 + (4 - NW) * 100 + Bt / 4 -
@@ -177,9 +178,9 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
             // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
             if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
             ev_begin(st);
-            hipLaunchKernelGGL(kern, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status, nfe, nsteps);
+            const hipError_t lerr = launch_persistent(fn, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status, nfe, nsteps);
             ev_end(st);
-            return PHX_OK;
+            return lerr == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         };
         // HALF: the last hidden tile has at most 8 live rows (H <= 40 with three tiles; rho16 in phx_mfma_v3common.inc)
         const char *eh = getenv("PHX_V3_HALF");   // diagnostic: 0 = full last tile also where half of it is padding

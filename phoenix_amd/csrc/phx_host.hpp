@@ -80,6 +80,26 @@ inline bool set_lds_resident(K kernel, size_t bytes, int threads, int grid)
     return set_lds_fn(fn, bytes) && fits_resident(fn, threads, bytes, grid);
 }
 
+// Persistent kernels whose workgroups wait for each other's rows need the whole grid resident at once.  Two ways to get
+// that: (default) a plain launch behind the occupancy check of fits_resident -- the library refuses a grid the device
+// cannot hold, and the engine's stream must not share the device with another long-running kernel (launch
+// planning); or PHX_COOP=1: hipLaunchCooperativeKernel, where the runtime itself guarantees co-residency.  The
+// cooperative path is NOT the default because it costs 18-19 us per launch on this stack (C4, same box, round 4:
+// forward 0.286 vs 0.268 ms, backward 0.616 vs 0.598 ms, step 0.939 vs 0.892 ms); it is there for deployments that
+// cannot keep other long kernels off the device.
+inline bool use_coop()
+{
+    const char *e = getenv("PHX_COOP");
+    return e && e[0] == '1';
+}
+template <typename... Args>
+inline hipError_t launch_persistent(const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
+{
+    void *argv[] = {(void *)&args...};
+    if (use_coop()) return hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned int)lds, st);
+    return hipLaunchKernel(fn, grid, block, argv, lds, st);
+}
+
 // diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
 inline thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 inline void ev_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }

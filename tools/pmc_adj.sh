@@ -7,7 +7,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_INSTS_BRANCH SQ_WAVES"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o run -- python3 $R/bench.py --workload ${2:-breast} --steps 6 --warmup 2 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o run -- python3 $R/bench.py --workload ${2:-breast} --steps 6 --warmup 2 --prewarm-seconds 0.02 --no-extras --no-cpu-baseline > $OUT/p$i.log 2>&1
 done
 cd $R
 python3 - <<PY
