@@ -195,6 +195,10 @@ int phx_hill_simulate(const int *code, const int *off, const int *len, const flo
 /* Diagnostic only: the next phx_odeint / phx_odeint_adjoint_backward call on this thread records these two
  * hipEvent_t immediately before and after its solve kernel (not around its memset nodes / reduce kernel). */
 void phx_debug_set_kernel_events(void *ev_start, void *ev_stop);
+/* Diagnostic only: a process-wide FIFO of such pairs; every following phx_odeint / phx_odeint_adjoint_backward launch
+ * (from any thread) takes the next pair.  (NULL, NULL) empties the queue.  Lets a bench time the solve kernels of
+ * ordinary back-to-back training steps (forward on the caller's thread, backward on an autograd worker thread). */
+void phx_debug_queue_kernel_events(void *ev_start, void *ev_stop);
 int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, size_t *offset,
                              int *n_workgroups, int *plan);
 /* Diagnostic only: which backward-solve kernel phx_odeint_adjoint_backward launches for this shape:

@@ -29,7 +29,7 @@ EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_worksp
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
            "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell",
            "phx_debug_adjoint_kernel_m", "phx_prior_z_bytes", "phx_prior_mse_save", "phx_prior_vjp_saved",
-           "phx_layout_params", "phx_debug_forward_kernel_m")
+           "phx_layout_params", "phx_debug_forward_kernel_m", "phx_debug_queue_kernel_events")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -85,6 +85,8 @@ def load():
     lib.phx_hill_simulate.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp, C.c_int, C.c_int, vp]
     lib.phx_debug_set_kernel_events.argtypes = [vp, vp]
     lib.phx_debug_set_kernel_events.restype = None
+    lib.phx_debug_queue_kernel_events.argtypes = [vp, vp]
+    lib.phx_debug_queue_kernel_events.restype = None
     lib.phx_debug_adjoint_kernel.argtypes = [C.c_int] * 5
     lib.phx_debug_adjoint_kernel_m.argtypes = [C.c_int] * 6
     lib.phx_odeint_calls_workspace_bytes.argtypes = [C.c_int] * 5

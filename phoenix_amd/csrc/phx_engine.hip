@@ -1274,6 +1274,13 @@ int phx_prior_targets_sell(const long long *sptr, const int *width, const int *r
     }
 }
 
+void phx_debug_queue_kernel_events(void *ev_start, void *ev_stop)
+{
+    std::lock_guard<std::mutex> lk(g_evq_mu);
+    if (!ev_start && !ev_stop) g_evq.clear();
+    else g_evq.emplace_back((hipEvent_t)ev_start, (hipEvent_t)ev_stop);
+}
+
 void phx_debug_set_kernel_events(void *ev_start, void *ev_stop)
 {
     g_ev_start = (hipEvent_t)ev_start;

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <tuple>
 #include <utility>
+#include <vector>
 
 #include "phx_solver.hpp"
 
@@ -102,7 +103,23 @@ inline hipError_t launch_persistent(const void *fn, dim3 grid, dim3 block, size_
 
 // diagnostic: optional HIP events recorded immediately around the next solve kernel (bench.py roofline timing)
 inline thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-inline void ev_begin(hipStream_t st) { if (g_ev_start) (void)hipEventRecord(g_ev_start, st); }
+// ... and a process-wide FIFO of such pairs (phx_debug_queue_kernel_events): successive solve launches take one pair each,
+// whichever thread issues them (the backward solve of a training step runs on an autograd worker thread), so a bench can
+// time the kernels of ordinary back-to-back steps instead of isolated launches
+inline std::mutex g_evq_mu;
+inline std::vector<std::pair<hipEvent_t, hipEvent_t>> g_evq;
+inline void ev_begin(hipStream_t st)
+{
+    if (!g_ev_start) {
+        std::lock_guard<std::mutex> lk(g_evq_mu);
+        if (!g_evq.empty()) {
+            g_ev_start = g_evq.front().first;
+            g_ev_stop = g_evq.front().second;
+            g_evq.erase(g_evq.begin());
+        }
+    }
+    if (g_ev_start) (void)hipEventRecord(g_ev_start, st);
+}
 inline void ev_end(hipStream_t st)
 {
     if (g_ev_stop) (void)hipEventRecord(g_ev_stop, st);
