@@ -84,6 +84,13 @@ typedef struct phx_solve_opts {
                            B/calls rows each (rows of a call contiguous), every call under its own shared step
                            controller -- the loop of find_gene_influences.py:64-77 in one launch.  0/1: one call.
                            The adjoint entry point ignores it. */
+    int ws_keep;        /* ABI 6.  0: the workspace may hold anything -- the call zero-fills its exchange buffers first (6-24 MB
+                           at breast scale, on `stream`, in front of the kernel).  1: the caller vouches that the PREVIOUS
+                           call that used this workspace was this same entry point with the same shape and options, is
+                           ordered before this one on `stream`, returned PHX_OK, and that nothing else wrote to the
+                           workspace since: kernels that keep two alternating sets of exchange buffers (the third-generation
+                           solve kernels) then skip the fill and clean the idle set themselves; every other kernel fills
+                           as with 0.  A first call on a workspace, or one after a shape change, must pass 0. */
 } phx_solve_opts;
 
 int phx_abi_version(void);

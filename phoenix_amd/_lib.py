@@ -21,7 +21,8 @@ class PhxGrads(C.Structure):
 
 class PhxSolveOpts(C.Structure):
     _fields_ = [("method", C.c_int), ("control", C.c_int), ("rtol", C.c_double), ("atol", C.c_double),
-                ("t_per_sample", C.c_int), ("t_is_f32", C.c_int), ("max_num_steps", C.c_longlong), ("calls", C.c_int)]
+                ("t_per_sample", C.c_int), ("t_is_f32", C.c_int), ("max_num_steps", C.c_longlong), ("calls", C.c_int),
+                ("ws_keep", C.c_int)]
 
 
 EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_workspace_bytes", "phx_rhs_forward",

@@ -86,7 +86,7 @@ int pick_chunk_adj3(int N, int H, int B, int T, int control, int method)
 size_t pp_adj3(const D1 &d) { return align_up((size_t)d.nblk * (4 * d.HT * 2 * 256) + d.N + 2 * d.H, 64); }
 
 struct Layout3 {
-    size_t total, cnt, part, zbuf, scratch, dtheta, prof, xbytes, wimg, hq;
+    size_t total, cnt, part, zbuf, part1, zbuf1, scratch, dtheta, prof, xbytes, wimg, hq;
 };
 
 Layout3 make_layout3(const D1 &d, bool grads)
@@ -98,7 +98,9 @@ Layout3 make_layout3(const D1 &d, bool grads)
     L.cnt = take(4096);
     L.part = take((size_t)d.TG * d.G * R * 64 * 8);
     L.zbuf = take((size_t)d.TG * R * 64 * 8);
-    L.xbytes = off - L.part;                                 // granule buffers are zeroed before every launch
+    L.xbytes = off - L.part;                                 // header + set 0: what a fill covers (phx_mfma_v3common.inc: XSet)
+    L.part1 = take((size_t)d.TG * d.G * R * 64 * 8);         // set 1: cleaned by the launch that works in set 0
+    L.zbuf1 = take((size_t)d.TG * R * 64 * 8);
     L.scratch = take((size_t)d.TG * d.G * NVEC_ADJ3 * d.ntg * d.NB * 512 * 4);
     L.dtheta = take(grads ? pp_adj3(d) * 4 * d.TG * d.NW : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
@@ -167,6 +169,8 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         w1.abort_flag = (unsigned int *)(base + L.cnt + 2048);
         w1.part = (unsigned long long *)(base + L.part);
         w1.zbuf = (unsigned long long *)(base + L.zbuf);
+        w1.part1 = (unsigned long long *)(base + L.part1);
+        w1.zbuf1 = (unsigned long long *)(base + L.zbuf1);
         w1.scratch = (float *)(base + L.scratch);
         w1.dtheta = (float *)(base + L.dtheta);
         const char *pe = getenv("PHX_PROF");   // 1: segment timers, 2: + per-block timers of the sweeps, 3: + of the quadrature
@@ -178,8 +182,11 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         const size_t lds = lds_bytes_adj3(d1);
         const long long PP = (long long)pp_adj3(d1);
         const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW;   // waves that own tiles
-        // counters + granule buffers are contiguous: one fill
-        if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+        // header + set 0 are contiguous: one fill -- unless the caller vouches for the workspace (ws_keep: the previous call
+        // on it was this one, same shape, same options) and the batch is one launch: the kernels then alternate between
+        // the two sets and clean the idle one themselves
+        const bool fill = !(o->ws_keep && chunk >= B);
+        if (fill && hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
         // every wave that owns a tile first-touches its whole partial (plain stores) in its first quadrature visit, or
         // zero-fills it at the end of the launch when its group never stepped; with T < 2 nobody runs either
         if (grads && T < 2 && hipMemsetAsync(w1.dtheta, 0, sizeof(float) * (size_t)PP * npart, st) != hipSuccess)

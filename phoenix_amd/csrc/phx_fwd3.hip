@@ -82,7 +82,7 @@ int pick_chunk_fwd3(int N, int H, int B, int T, int control, int method)
 }
 
 struct LayoutF3 {
-    size_t total, cnt, part, zbuf, scratch, prof, xbytes, wimg;
+    size_t total, cnt, part, zbuf, part1, zbuf1, scratch, prof, xbytes, wimg;
 };
 
 LayoutF3 make_layout_f3(const D1 &d)
@@ -94,7 +94,9 @@ LayoutF3 make_layout_f3(const D1 &d)
     L.cnt = take(4096);
     L.part = take((size_t)d.TG * d.G * R * 64 * 8);
     L.zbuf = take((size_t)d.TG * R * 64 * 8);
-    L.xbytes = off - L.part;                                 // granule buffers are zeroed before every launch
+    L.xbytes = off - L.part;                                 // header + set 0: what a fill covers (phx_mfma_v3common.inc: XSet)
+    L.part1 = take((size_t)d.TG * d.G * R * 64 * 8);         // set 1: cleaned by the launch that works in set 0
+    L.zbuf1 = take((size_t)d.TG * R * 64 * 8);
     L.scratch = take((size_t)d.TG * d.G * NVEC_FWD3 * d.ntg * d.NB * 512 * 4);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
@@ -160,13 +162,17 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
         w1.abort_flag = (unsigned int *)(base + L.cnt + 2048);
         w1.part = (unsigned long long *)(base + L.part);
         w1.zbuf = (unsigned long long *)(base + L.zbuf);
+        w1.part1 = (unsigned long long *)(base + L.part1);
+        w1.zbuf1 = (unsigned long long *)(base + L.zbuf1);
         w1.scratch = (float *)(base + L.scratch);
         const char *pe = getenv("PHX_PROF");
         w1.prof = (pe && atoi(pe) >= 1) ? (unsigned long long *)(base + L.prof) : nullptr;
         w1.wimg = (const float *)(base + L.wimg);
         const size_t lds = lds_bytes_fwd3(d1);
-        // counters + granule buffers are contiguous: one fill
-        if (hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
+        // header + set 0 are contiguous: one fill -- unless the caller vouches for the workspace (ws_keep) and the batch is
+        // one launch (see adj3_run)
+        const bool fill = !(o->ws_keep && chunk >= B);
+        if (fill && hipMemsetAsync(w1.cnt, 0, L.part - L.cnt + L.xbytes, st) != hipSuccess) return PHX_ERR_LAUNCH;
         const dim3 grid1(d1.TG * d1.G), blk1(64 * d1.NW);
         if (p->wimg) w1.wimg = (const float *)p->wimg;   // packed once by the caller for these parameter values
         else

@@ -851,6 +851,52 @@ def test_engine_variants_agree_with_oracle(pa, dev, oracle, monkeypatch, variant
         assert relerr(gg[k], gr_ref[k]) < gtol, k
 
 
+def test_repeated_solves_on_a_kept_workspace_are_bitwise_the_first(pa, dev):
+    """phx_solve_opts.ws_keep: from the second identical call on, the engine vouches for its cached workspace and the
+    third-generation kernels skip the fill of their exchange buffers (two sets used alternately, the idle one cleaned by
+    the running launch).  Every repetition -- an odd and an even number of launches since the last fill, after another
+    shape used the same workspace, after a launch in which every trajectory failed at once -- must return bitwise what a
+    freshly filled workspace returns."""
+    from phoenix_amd import _lib, engine
+    N, H = 2300, 24
+    p = rand_params(N, H, seed=77, std=0.05)
+    net = make_net(pa, dev, p)
+    pe = engine.params_cached(*pa.odenet.params_of(net))
+    r = np.random.RandomState(6)
+
+    def problem(B):
+        y0 = torch.from_numpy(np.clip(r.randn(B, N) * 0.15 + 0.5, 0.03, 1.07).astype(np.float32)).to(dev)
+        t = torch.from_numpy(np.stack([np.array([0.0, 0.2 + 0.01 * (b % 7)]) for b in range(B)]).astype(np.float32)).to(dev)
+        G = torch.from_numpy(r.randn(2, B, N).astype(np.float32)).to(dev)
+        return y0, t, G
+
+    def run(prob, max_steps=0):
+        y0, t, G = prob
+        sol, st, _, ns = engine.solve_forward(pe, y0, t, "dopri5", _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, 2, max_steps)
+        adj, gr, st2, _, ns2 = engine.solve_adjoint(pe, t, sol, G, "dopri5", _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, 2,
+                                                    max_num_steps=max_steps)
+        return sol.clone(), adj.clone(), gr.flat.clone(), int(st.max()), int(st2.max())
+
+    assert _lib.load().phx_debug_adjoint_kernel_m(N, H, 40, 2, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS["dopri5"]) == 3
+    pa_, pb_ = problem(40), problem(70)
+    engine.forget_workspaces()
+    ref_a = run(pa_)
+    assert ref_a[3] == 0 and ref_a[4] == 0
+    for _ in range(3):                      # kept: sets 1, 0, 1
+        got = run(pa_)
+        assert all(torch.equal(x, y) for x, y in zip(got[:3], ref_a[:3]))
+    engine.forget_workspaces()
+    ref_b = run(pb_)
+    for _ in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(run(pb_)[:3], ref_b[:3]))
+    for _ in range(2):                      # back to the first shape: filled once, then kept
+        assert all(torch.equal(x, y) for x, y in zip(run(pa_)[:3], ref_a[:3]))
+    failed = run(pa_, max_steps=1)          # every trajectory stops after one step: status max_num_steps exceeded
+    assert failed[3] == 1
+    for _ in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(run(pa_)[:3], ref_a[:3]))
+
+
 @pytest.mark.parametrize("B", [64, 200])
 def test_step_counts_of_the_third_generation_kernels_match_the_first(pa, dev, oracle, monkeypatch, B):
     """Canary for the wrong-step-size signature of DESIGN.md section 2 ("one signature"): trajectories 12..15 of every
@@ -958,6 +1004,7 @@ def test_chunked_hidden_layer_shared_control_vs_oracle(pa, dev, oracle, N, H, B,
         try:
             for rep in range(2):     # the second pass runs on workspaces that exist and were filled with junk
                 from phoenix_amd import engine as _eng
+                _eng.forget_workspaces()               # this test writes into the workspaces behind the engine's back
                 for buf in _eng._ws_cache.values():
                     buf.view(torch.float32)[: buf.numel() // 4].fill_(777.0)
                 zero_grads(net)
@@ -1267,6 +1314,7 @@ def test_random_shapes_mfma_engine_agrees_with_valu_engine(pa, dev, seed):
         try:
             for rep in range(2):     # the second pass runs on workspaces that exist and were filled with junk
                 from phoenix_amd import engine as _eng
+                _eng.forget_workspaces()               # this test writes into the workspaces behind the engine's back
                 for buf in _eng._ws_cache.values():
                     buf.view(torch.float32)[: buf.numel() // 4].fill_(777.0)
                 zero_grads(net)
@@ -1342,6 +1390,7 @@ def test_results_do_not_depend_on_what_the_workspace_held_before(pa, dev, monkey
     cot = torch.from_numpy(rs.randn(B, N).astype(np.float32)).to(dev)
 
     def poison(value):
+        engine.forget_workspaces()                     # the engine would otherwise vouch for them (ws_keep)
         for buf in engine._ws_cache.values():
             buf.view(torch.float32)[: buf.numel() // 4].fill_(value)
 
