@@ -1068,7 +1068,8 @@ def test_prior_backward_from_saved_hidden_rows_equals_recomputation(pa, dev, N, 
             assert torch.equal(getattr(g0, k), getattr(g1, k)), k
 
 
-@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100), (300, 131, 90)])
+@pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 333), (600, 120, 70), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100), (300, 131, 90),
+                                   (11165, 40, 10000)])   # the last one: the prior batch of config C4 at its full size
 def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the exchange-free
     MFMA chains of phx_mfma_batch.inc (forward from 1024 rows up, parameter gradients for any batch when the input
