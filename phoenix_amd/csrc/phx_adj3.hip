@@ -82,7 +82,7 @@ int pick_chunk_adj3(int N, int H, int B, int T, int control, int method)
     return 0;
 }
 
-// floats of one wave's partial: accumulator-native [gene block][4 HT x 2][64] float4, then dg [N], dbs [H], dbp [H]
+// floats of one batch group's partial: accumulator-native [gene block][4 HT x 2][64] float4, then dg [N], dbs [H], dbp [H]
 size_t pp_adj3(const D1 &d) { return align_up((size_t)d.nblk * (4 * d.HT * 2 * 256) + d.N + 2 * d.H, 64); }
 
 struct Layout3 {
@@ -102,7 +102,7 @@ Layout3 make_layout3(const D1 &d, bool grads)
     L.part1 = take((size_t)d.TG * d.G * R * 64 * 8);         // set 1: cleaned by the launch that works in set 0
     L.zbuf1 = take((size_t)d.TG * R * 64 * 8);
     L.scratch = take((size_t)d.TG * d.G * NVEC_ADJ3 * d.ntg * d.NB * 512 * 4);
-    L.dtheta = take(grads ? pp_adj3(d) * 4 * d.TG * d.NW : 0);
+    L.dtheta = take(grads ? pp_adj3(d) * 4 * d.TG : 0);
     L.prof = take((size_t)d.TG * d.G * 16 * 8);
     L.wimg = take((size_t)d.nblk * blk_floats_ch(d.HT, d.H) * 4);
     // transposed hidden rows of the seven ring slots, shared by a group's workgroups: [group][tile][7][4 HT][64] float4
@@ -181,7 +181,7 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         w1.hq = (float *)(base + L.hq);
         const size_t lds = lds_bytes_adj3(d1);
         const long long PP = (long long)pp_adj3(d1);
-        const int npart = d1.TG == 1 ? (d1.ntg + d1.TPW - 1) / d1.TPW : d1.TG * d1.NW;   // waves that own tiles
+        const int npart = d1.TG;   // one partial per workgroup of a gene tile = per batch group (k1_solve_adj3: quad_accept)
         // header + set 0 are contiguous: one fill -- unless the caller vouches for the workspace (ws_keep: the previous call
         // on it was this one, same shape, same options) and the batch is one launch: the kernels then alternate between
         // the two sets and clean the idle one themselves
