@@ -994,7 +994,7 @@ constexpr int BATCH_FWD_MIN_ROWS = 1024;   // smaller batches: the pass-structur
 struct PlanBatch {
     D1 d;              // kernel A: gene tiles (NB blocks resident in LDS) x TG sweep groups
     size_t ldsA;
-    int ntiles, chunk_tiles, KS, slabs;
+    int ntiles, chunk_tiles, chunk_tiles2, KS, pgW, pgG4, slabs;   // KS / pgW: partial buffers / workgroups of kernel C; chunk_tiles2: launches whose partials have half the rows (u | v or dz only)
     long long Kp;
     size_t part, hdt, dtheta, total;   // workspace offsets
     size_t zl, losspart, total_fwd;    // forward path: per-chunk z rows, per-wave loss partials (fused MSE head)
@@ -1008,7 +1008,7 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     if (const char *e = getenv("PHX_PGRAD")) if (strcmp(e, "v1") == 0) return false;
     const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;     // hidden chunks as in plan_v1: one chain per chunk
     const int HT = Hc <= 48 ? 3 : 8;
-    const size_t blkbytes = (size_t)blk_floats(HT, Hc) * 4;
+    const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4;   // the slot size of the packed images (stage_block_weights)
     if (blkbytes > LDS_BUDGET) return false;
     const int nblk = (N + 31) / 32;
     const int NB = (int)std::min<size_t>(std::min<size_t>(LDS_BUDGET / blkbytes, 6), (size_t)nblk);
@@ -1022,28 +1022,80 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     out->ntiles = (B + 15) / 16;
     out->Kp = (long long)out->ntiles * 16;
     const size_t per_tile = (size_t)16 * HT * d.G * 64 * 4;           // FR rows x G members x 64 lanes
-    // partials of one chunk: ~128 MB (Infinity Cache resident), but never fewer than 64 tiles per weight staging
-    out->chunk_tiles = (int)std::min<size_t>((size_t)out->ntiles, std::max<size_t>(64, ((size_t)128 << 20) / per_tile));
-    out->slabs = (N + 63) / 64;
-    out->KS = std::max(1, std::min(8, (4 * cus) / out->slabs));   // ~4 workgroups per CU hide the tile-load latency
-    if (const char *e = getenv("PHX_PGRAD_KS")) out->KS = std::max(1, std::min(16, atoi(e)));
+    // partials of one chunk: ~128 MB (Infinity Cache resident), but never fewer than 64 tiles per weight staging; the
+    // chunks of a batch are made equal (625 tiles: 2 x 313 instead of 370 + 255: the sweep groups stay balanced)
+    auto even_chunks = [&](size_t cmax) {
+        const size_t nch = ((size_t)out->ntiles + cmax - 1) / cmax;
+        return (int)(((size_t)out->ntiles + nch - 1) / nch);
+    };
+    out->chunk_tiles = even_chunks(std::max<size_t>(64, ((size_t)128 << 20) / per_tile));
+    out->chunk_tiles2 = even_chunks(std::max<size_t>(64, ((size_t)256 << 20) / per_tile));
+    const size_t part_bytes = std::max(per_tile * out->chunk_tiles, per_tile / 2 * out->chunk_tiles2);
+    // kernel C: 64-gene slabs, four workgroups per CU.  (PHX_PGRAD_G4=8: 128-gene slabs, two per CU, half the A-operand
+    // reads per MFMA -- measured slower at C4, 570 against 522 us: those reads are not what paces the kernel.)
+    out->pgG4 = 4;
+    if (const char *e = getenv("PHX_PGRAD_G4")) out->pgG4 = (atoi(e) == 8 && HT == 3) ? 8 : 4;
+    out->slabs = (N + 16 * out->pgG4 - 1) / (16 * out->pgG4);
+    {   // kernel C: as many workgroups per CU as its registers allow take equal ranges of the (slab, step) units; a
+        // slab is then shared by at most KS of them (k2_pgrad_contract); never fewer than 8 steps per workgroup
+        int per_cu = out->pgG4 == 8 ? 2 : 4;
+        if (const char *e = getenv("PHX_PGRAD_WGS")) per_cu = std::max(1, std::min(8, atoi(e)));
+        const long long U = (long long)out->slabs * out->ntiles;
+        const long long W = std::max<long long>(1, std::min<long long>((long long)per_cu * cus, std::max<long long>(out->slabs, U / 8)));
+        const long long per = std::max<long long>(1, U / W);
+        out->pgW = (int)W;
+        out->KS = (int)std::min<long long>(out->ntiles, (out->ntiles + per - 1) / per + 1);
+    }
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t PP = align_up((size_t)4 * H * N + N + 2 * H, 4);
-    out->part = take(per_tile * out->chunk_tiles);
+    out->part = take(part_bytes);
     out->hdt = take((size_t)4 * 16 * HT * out->Kp * 4);
     out->dtheta = take(PP * 4 * out->KS);
     out->total = off;
     out->zl4 = take((size_t)out->chunk_tiles * 4 * HT * 4 * 64 * 4);
     out->dgpart = take((size_t)d.TG * 4 * N * 4);
     out->total_vjp = off;
-    off = align_up(per_tile * out->chunk_tiles, 256);   // forward path reuses the partial buffer (half as many rows)
-    out->zl = take((size_t)out->chunk_tiles * 2 * HT * 4 * 64 * 4);
-    out->losspart = take((size_t)d.TG * d.G * 8 * sizeof(double));
+    off = align_up(part_bytes, 256);   // forward path reuses the partial buffer (half as many rows: chunk_tiles2)
+    out->zl = take((size_t)out->chunk_tiles2 * 2 * HT * 4 * 64 * 4);
+    out->losspart = take((size_t)d.TG * d.G * 16 * sizeof(double));   // one slot per wave (<= 16 waves per workgroup)
     out->total_fwd = off;
     return true;
 }
 
+
+// The Net of the batch kernels: with the caller's packed weight images when their tiling is the batch kernels' own
+// (phx_weight_image_bytes uses solve_ht: 7 hidden tiles for a chunked H <= 224, where plan_batch takes 8)
+// threads per workgroup of the sweep kernels of the batch chain (PHX_BATCH_WAVES: diagnostic, fewer waves than compiled for)
+template <int HT>
+inline int batch_threads(bool expansion = false)
+{
+    int t = expansion ? BatchThreads<HT>::D : BatchThreads<HT>::A;
+    if (const char *e = getenv("PHX_BATCH_WAVES")) t = std::max(64, std::min(t, 64 * atoi(e)));
+    return t;
+}
+
+inline Net batch_net(const PlanBatch &pb, const phx_params *p)
+{
+    Net n = to_net(p);
+    n.wimg = (p->wimg && solve_ht(pb.d.HC, pb.d.Hc) == pb.d.HT && !getenv("PHX_BATCH_NO_WIMG")) ? (const float *)p->wimg : nullptr;
+    return n;
+}
+
+template <int HT>
+inline void launch_pgrad_contract(const PlanBatch &pb, hipStream_t st, const Net &net, const float *y, const float *cot,
+                                  const float *hdt, float *dth, long long PP, int hb, int hc, int full)
+{
+    if constexpr (HT == 3) {
+        if (pb.pgG4 == 8) {
+            hipLaunchKernelGGL((k2_pgrad_contract<HT, 8>), dim3(pb.pgW), dim3(256), 0, st, net, y, cot, hdt, dth, pb.d.B,
+                               pb.ntiles, pb.Kp, pb.KS, PP, hb, hc, full);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k2_pgrad_contract<HT, 4>), dim3(pb.pgW), dim3(256), 0, st, net, y, cot, hdt, dth, pb.d.B, pb.ntiles,
+                       pb.Kp, pb.KS, PP, hb, hc, full);
+}
 
 // zsaved (optional, unchunked hidden layer only): the reduced hidden rows the forward chain of the same step kept
 // (phx_prior_mse_save) -- kernel A then contracts the cotangent only (half its MFMAs and partial rows)
@@ -1058,20 +1110,20 @@ int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y,
     if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA) || !set_lds(k2_hidden_partials<HT, 2>, pb.ldsA)) return PHX_ERR_LAUNCH;
     for (int ch = 0; ch < pb.d.HC; ++ch) {      // hidden chunks are independent slices of the same gradient
         const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
-        for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
-            const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+        const int ct = zsaved ? pb.chunk_tiles2 : pb.chunk_tiles;
+        for (int t0 = 0; t0 < pb.ntiles; t0 += ct) {
+            const int nt = std::min(ct, pb.ntiles - t0);
             if (zsaved)
-                hipLaunchKernelGGL((k2_hidden_partials<HT, 2>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
-                                   st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
+                hipLaunchKernelGGL((k2_hidden_partials<HT, 2>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()), pb.ldsA,
+                                   st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc);
             else
-                hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256),
-                                   pb.ldsA, st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc);
+                hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()),
+                                   pb.ldsA, st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
                                pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, const_cast<float *>(zsaved));
         }
-        hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt, dth,
-                           pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc);
+        launch_pgrad_contract<HT>(pb, st, to_net(p), y, cot, hdt, dth, PP, hb, hc, 0);
     }
     if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     return launch_reduce_grads(dth, pb.KS, PP, p->N, p->H, grads, grads->overwrite, st) ? PHX_OK : PHX_ERR_LAUNCH;
@@ -1094,19 +1146,18 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
         const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
         for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
             const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
-            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(HT == 3 ? 512 : 256), pb.ldsA,
-                               st, to_net(p), pb.d, y, cot, part, t0, nt, hb, hc, full);
+            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()), pb.ldsA,
+                               st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc, full);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
                                pb.d.G, t0, nt, pb.Kp, hb, hc, want_e ? zl4 : (float *)nullptr);
             if (want_e)
-                hipLaunchKernelGGL((k2_expand_vjp<HT>), dim3(pb.d.TG * pb.d.G), dim3(256), pb.ldsA, st, to_net(p), pb.d, y,
+                hipLaunchKernelGGL((k2_expand_vjp<HT>), dim3(pb.d.TG * pb.d.G), dim3(256), pb.ldsA, st, batch_net(pb, p), pb.d, y,
                                    cot, zl4, vjp_y, f_out, (grads && full) ? dgp : (float *)nullptr, prior_only, t0, nt,
                                    (t0 == 0 && ch == 0) ? 1 : 0, hb, hc);
         }
         if (grads)
-            hipLaunchKernelGGL((k2_pgrad_contract<HT>), dim3(pb.slabs * pb.KS), dim3(256), 0, st, to_net(p), y, cot, hdt,
-                               dth, pb.d.B, pb.ntiles, pb.Kp, pb.KS, PP, hb, hc, full);
+            launch_pgrad_contract<HT>(pb, st, to_net(p), y, cot, hdt, dth, PP, hb, hc, full);
     }
     if (grads) {
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
@@ -1127,25 +1178,25 @@ int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *
     float *part = (float *)(base + pb.part), *zl = (float *)(base + pb.zl);
     double *loss_part = (double *)(base + pb.losspart);
     const float cot_scale = (float)(2.0 / ((double)pb.d.B * (double)p->N));
-    if (target && hipMemsetAsync(loss_part, 0, sizeof(double) * (size_t)pb.d.TG * pb.d.G * 8, st) != hipSuccess)
+    if (target && hipMemsetAsync(loss_part, 0, sizeof(double) * (size_t)pb.d.TG * pb.d.G * 16, st) != hipSuccess)
         return PHX_ERR_LAUNCH;
     if (!set_lds(k2_hidden_partials<HT, false>, pb.ldsA) || !set_lds(k2_expand<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
-    const dim3 grid(pb.d.TG * pb.d.G), blk(HT == 3 ? 512 : 256);
-    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles) {
-        const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+    const dim3 grid(pb.d.TG * pb.d.G), blk(batch_threads<HT>()), blkD(batch_threads<HT>(true));
+    for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles2) {
+        const int nt = std::min(pb.chunk_tiles2, pb.ntiles - t0);
         for (int ch = 0; ch < pb.d.HC; ++ch) {
             const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
-            hipLaunchKernelGGL((k2_hidden_partials<HT, false>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y,
+            hipLaunchKernelGGL((k2_hidden_partials<HT, false>), grid, blk, pb.ldsA, st, batch_net(pb, p), pb.d, y,
                                (const float *)nullptr, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
                                pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, zsave);
-            hipLaunchKernelGGL((k2_expand<HT>), grid, blk, pb.ldsA, st, to_net(p), pb.d, y, zl, out, prior_only, t0, nt, hb,
+            hipLaunchKernelGGL((k2_expand<HT>), grid, blkD, pb.ldsA, st, batch_net(pb, p), pb.d, y, zl, out, prior_only, t0, nt, hb,
                                hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0, target, cot_scale, loss_part);
         }
     }
     if (target) {
-        const int nslots = pb.d.TG * pb.d.G * (HT == 3 ? 8 : 4);
+        const int nslots = pb.d.TG * pb.d.G * (batch_threads<HT>(true) / 64);
         hipLaunchKernelGGL(k2_loss_finish, dim3(1), dim3(64), 0, st, loss_part, nslots,
                            1.0 / ((double)pb.d.B * (double)p->N), loss);
     }

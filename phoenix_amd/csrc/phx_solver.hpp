@@ -13,6 +13,7 @@ namespace phxt {   // plain types that cross translation units (kernel signature
 struct Net {
     const float *Ws, *bs, *Wp, *bp, *WaT, *g;
     int N, H;
+    const float *wimg;   // packed LDS weight images of these values (phx_params.wimg) or null; set by the batch launchers only
 };
 
 struct SolveCfg {
