@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PHX_ABI_VERSION 6
+#define PHX_ABI_VERSION 7
 
 /* ODENet parameters (odenet.py:42-82), gene-contiguous: every matrix is [rows, N] row-major.
  *   Ws  [H, N]   net_sums.linear_out.weight            (reference layout as is)
@@ -171,14 +171,17 @@ int phx_prior_targets_sell(const long long *sptr, const int *width, const int *r
 int phx_prior_mse(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
                   void *workspace, size_t workspace_bytes, void *stream);
 
-/* The same step with the hidden rows kept for the backward (ABI 5).  The forward chain of phx_prior_mse reduces the
- * hidden rows z = [Ws a(X) + bs ; exp(Wp l(X) + bp)] of every row of X anyway; phx_prior_mse_save also writes them to
- * `z_save` (phx_prior_z_bytes(N, H, B) bytes, device, caller-owned; 0 = this shape has no such path: H > 128 or the
- * batch chain cannot be planned), and phx_prior_vjp_saved computes the parameter gradients of
- * sum(cot * prior_only_forward(X)) -- what phx_rhs_vjp(prior_only = 1, vjp_y = NULL) computes -- WITHOUT recomputing
- * them: its first kernel contracts only the cotangent (half the MFMAs and partial rows).  Same workspaces as
- * phx_prior_mse / phx_rhs_vjp.  Replaces nothing new in the reference: it is train_insilico.py:134-138 again, with
- * autograd's saved activations made explicit.                                                                       */
+/* The same step with the hidden rows kept for the backward (ABI 5; what is kept changed in ABI 7).  The forward chain of
+ * phx_prior_mse reduces the hidden rows z = [Ws a(X) + bs ; exp(Wp l(X) + bp)] of every row of X anyway, and its last
+ * kernel holds the loss cotangent in registers.  phx_prior_mse_save also contracts that cotangent with the rows of Wa
+ * there and writes the four hidden sections  du | dv | z_u | z_p  of every row ([4][16 HT][16 ceil(B / 16)] floats, the
+ * operand layout of the gradient contraction) to `z_save` (phx_prior_z_bytes(N, H, B) bytes, device, caller-owned; 0 =
+ * this shape has no such path: H > 128 or the batch chain cannot be planned).  phx_prior_vjp_saved then computes the
+ * parameter gradients of sum(cot * prior_only_forward(X)) -- what phx_rhs_vjp(prior_only = 1, vjp_y = NULL) computes --
+ * with the contraction kernel alone: `cot` must be the cotangent phx_prior_mse_save wrote (the caller scales the
+ * gradients by d loss afterwards; the saved sections are those of d loss = 1).  Same workspaces as phx_prior_mse /
+ * phx_rhs_vjp.  Replaces nothing new in the reference: it is train_insilico.py:134-138 again, with autograd's saved
+ * activations made explicit.                                                                                          */
 size_t phx_prior_z_bytes(int N, int H, int B);
 int phx_prior_mse_save(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,
                        float *z_save, void *workspace, size_t workspace_bytes, void *stream);

@@ -97,6 +97,6 @@ def load():
     lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
     lib.phx_layout_params.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.phx_debug_forward_kernel_m.argtypes = [C.c_int] * 6
-    assert lib.phx_abi_version() == 6
+    assert lib.phx_abi_version() == 7
     _LIB = lib
     return lib

@@ -1097,33 +1097,28 @@ inline void launch_pgrad_contract(const PlanBatch &pb, hipStream_t st, const Net
                        pb.Kp, pb.KS, PP, hb, hc, full);
 }
 
-// zsaved (optional, unchunked hidden layer only): the reduced hidden rows the forward chain of the same step kept
-// (phx_prior_mse_save) -- kernel A then contracts the cotangent only (half its MFMAs and partial rows)
+// hsaved (optional, unchunked hidden layer only): the four hidden sections du | dv | z_u | z_p of every row, kept by the
+// forward chain of the same step (phx_prior_mse_save) in kernel C's operand layout -- kernels A and R are not run
 template <int HT>
 int launch_batch_pgrad(const PlanBatch &pb, const phx_params *p, const float *y, const float *cot, const phx_grads *grads,
-                       char *base, hipStream_t st, const float *zsaved = nullptr)
+                       char *base, hipStream_t st, const float *hsaved = nullptr)
 {
-    if (pb.d.HC != 1) zsaved = nullptr;
+    if (pb.d.HC != 1) hsaved = nullptr;
     float *part = (float *)(base + pb.part), *hdt = (float *)(base + pb.hdt), *dth = (float *)(base + pb.dtheta);
     const long long PP = (long long)align_up((size_t)4 * p->H * p->N + p->N + 2 * p->H, 4);
     if (hipMemsetAsync(dth, 0, sizeof(float) * (size_t)PP * pb.KS, st) != hipSuccess) return PHX_ERR_LAUNCH;
-    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA) || !set_lds(k2_hidden_partials<HT, 2>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    if (!set_lds(k2_hidden_partials<HT, true>, pb.ldsA)) return PHX_ERR_LAUNCH;
     for (int ch = 0; ch < pb.d.HC; ++ch) {      // hidden chunks are independent slices of the same gradient
         const int hb = ch * pb.d.Hc, hc = std::min(pb.d.Hc, p->H - hb);
-        const int ct = zsaved ? pb.chunk_tiles2 : pb.chunk_tiles;
-        for (int t0 = 0; t0 < pb.ntiles; t0 += ct) {
-            const int nt = std::min(ct, pb.ntiles - t0);
-            if (zsaved)
-                hipLaunchKernelGGL((k2_hidden_partials<HT, 2>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()), pb.ldsA,
-                                   st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc);
-            else
-                hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()),
-                                   pb.ldsA, st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc);
+        for (int t0 = 0; t0 < pb.ntiles && !hsaved; t0 += pb.chunk_tiles) {
+            const int nt = std::min(pb.chunk_tiles, pb.ntiles - t0);
+            hipLaunchKernelGGL((k2_hidden_partials<HT, true>), dim3(pb.d.TG * pb.d.G), dim3(batch_threads<HT>()),
+                               pb.ldsA, st, batch_net(pb, p), pb.d, y, cot, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, hdt,
-                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, const_cast<float *>(zsaved));
+                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, (float *)nullptr);
         }
-        launch_pgrad_contract<HT>(pb, st, to_net(p), y, cot, hdt, dth, PP, hb, hc, 0);
+        launch_pgrad_contract<HT>(pb, st, to_net(p), y, cot, hsaved ? hsaved : hdt, dth, PP, hb, hc, 0);
     }
     if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     return launch_reduce_grads(dth, pb.KS, PP, p->N, p->H, grads, grads->overwrite, st) ? PHX_OK : PHX_ERR_LAUNCH;
@@ -1169,18 +1164,23 @@ int launch_batch_vjp(const PlanBatch &pb, const phx_params *p, const float *y, c
     return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
 }
 
-// prior_only_forward / ODENet.forward on a large batch: A (u, v partials) -> R (z rows) -> D (expansion) per chunk
+// prior_only_forward / ODENet.forward on a large batch: A (u, v partials) -> R (z rows) -> D (expansion) per chunk.
+// hsave (phx_prior_mse_save; unchunked hidden layer): D also contracts the loss cotangent with the Wa rows (dz partials, in
+// the partial buffer A has just been reduced from) and a second R writes the four hidden sections du | dv | z_u | z_p of
+// the chunk's rows into `hsave` ([4][16 HT][Kp], kernel C's A operand): the backward of the step is kernel C alone.
 template <int HT>
 int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *y, float *out, int prior_only, char *base,
-                         hipStream_t st, const float *target = nullptr, float *loss = nullptr, float *zsave = nullptr)
+                         hipStream_t st, const float *target = nullptr, float *loss = nullptr, float *hsave = nullptr)
 {
-    if (pb.d.HC != 1) zsave = nullptr;   // (the saved rows are those of an unchunked hidden layer)
+    if (pb.d.HC != 1 || !target) hsave = nullptr;   // (the saved rows are those of an unchunked hidden layer)
     float *part = (float *)(base + pb.part), *zl = (float *)(base + pb.zl);
     double *loss_part = (double *)(base + pb.losspart);
     const float cot_scale = (float)(2.0 / ((double)pb.d.B * (double)p->N));
     if (target && hipMemsetAsync(loss_part, 0, sizeof(double) * (size_t)pb.d.TG * pb.d.G * 16, st) != hipSuccess)
         return PHX_ERR_LAUNCH;
-    if (!set_lds(k2_hidden_partials<HT, false>, pb.ldsA) || !set_lds(k2_expand<HT>, pb.ldsA)) return PHX_ERR_LAUNCH;
+    if (!set_lds(k2_hidden_partials<HT, false>, pb.ldsA) || !set_lds(k2_expand<HT, false>, pb.ldsA) ||
+        !set_lds(k2_expand<HT, true>, pb.ldsA))
+        return PHX_ERR_LAUNCH;
     const dim3 grid(pb.d.TG * pb.d.G), blk(batch_threads<HT>()), blkD(batch_threads<HT>(true));
     for (int t0 = 0; t0 < pb.ntiles; t0 += pb.chunk_tiles2) {
         const int nt = std::min(pb.chunk_tiles2, pb.ntiles - t0);
@@ -1190,9 +1190,17 @@ int launch_batch_forward(const PlanBatch &pb, const phx_params *p, const float *
                                (const float *)nullptr, part, t0, nt, hb, hc);
             const int tasks = nt * HT * 4;
             hipLaunchKernelGGL((k2_hidden_reduce<HT, false>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part, zl,
-                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, zsave);
-            hipLaunchKernelGGL((k2_expand<HT>), grid, blkD, pb.ldsA, st, batch_net(pb, p), pb.d, y, zl, out, prior_only, t0, nt, hb,
-                               hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0, target, cot_scale, loss_part);
+                               pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, (float *)nullptr);
+            if (hsave) {
+                hipLaunchKernelGGL((k2_expand<HT, true>), grid, blkD, pb.ldsA, st, batch_net(pb, p), pb.d, y, zl, out,
+                                   prior_only, t0, nt, hb, hc, 1, 1, target, cot_scale, loss_part, part);
+                hipLaunchKernelGGL((k2_hidden_reduce<HT, true>), dim3((tasks + 3) / 4), dim3(256), 0, st, to_net(p), part,
+                                   hsave, pb.d.G, t0, nt, pb.Kp, hb, hc, (float *)nullptr, zl, 1);
+            } else {
+                hipLaunchKernelGGL((k2_expand<HT, false>), grid, blkD, pb.ldsA, st, batch_net(pb, p), pb.d, y, zl, out,
+                                   prior_only, t0, nt, hb, hc, ch == 0 ? 1 : 0, ch == pb.d.HC - 1 ? 1 : 0, target, cot_scale,
+                                   loss_part);
+            }
         }
     }
     if (target) {
@@ -1264,7 +1272,7 @@ size_t phx_prior_z_bytes(int N, int H, int B)
 {
     PlanBatch pb;
     if (N <= 0 || H <= 0 || B <= 0 || !plan_batch(N, H, B, &pb) || pb.d.HC != 1) return 0;
-    return (size_t)pb.ntiles * 2 * pb.d.HT * 4 * 64 * sizeof(float);
+    return (size_t)4 * 16 * pb.d.HT * pb.Kp * sizeof(float);   // du | dv | z_u | z_p, [16 HT] rows x Kp trajectories each
 }
 
 int phx_prior_mse_save(const phx_params *p, const float *X, const float *target, int B, float *cot, float *loss,

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.phx_abi_version() == 6
+    assert lib.phx_abi_version() == 7
     assert lib.phx_status_string(2).decode() == "underflow in dt"
 
 
