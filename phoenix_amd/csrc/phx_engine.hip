@@ -905,7 +905,7 @@ Layout1 make_layout1(const D1 &d, int ftiles, bool grads, int zslots = 1)
 W1 make_w1(void *base, const Layout1 &L)
 {
     char *p = (char *)base;
-    W1 w;
+    W1 w{};
     w.cnt = (unsigned long long *)(p + L.cnt);
     w.abort_flag = (unsigned int *)(p + L.cnt + 2048);
     w.part = (unsigned long long *)(p + L.part);

@@ -167,6 +167,7 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
         w1.scratch = (float *)(base + L.scratch);
         const char *pe = getenv("PHX_PROF");
         w1.prof = (pe && atoi(pe) >= 1) ? (unsigned long long *)(base + L.prof) : nullptr;
+        w1.prof_level = pe ? atoi(pe) : 0;
         w1.wimg = (const float *)(base + L.wimg);
         const size_t lds = lds_bytes_fwd3(d1);
         // header + set 0 are contiguous: one fill -- unless the caller vouches for the workspace (ws_keep) and the batch is

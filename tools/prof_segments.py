@@ -48,7 +48,7 @@ fwd3 = which == "fwd" and wl["method"] == "dopri5" and H <= 48 and os.environ.ge
 if fwd3:
     names = ["other (barriers, tails)", "sweeps: P1 only", "sweeps: fused P2+P1", "reduce-scatter", "gather hidden rows (1st tile)",
              "sweeps: P2 only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "accept pass (dense output)",
-             "-", "-", "-", "-", "-"]
+             "-", "block: tile wait", "block: consume tiles + requests", "block: P2 + k", "block: input + act + P1"]
 if kern == 3:
     names = ["other (barriers, tails)", "sweeps: P1' only", "sweeps: fused P2'+P1'", "reduce-scatter (+FSAL rows)", "gather hidden rows (1st tile)",
              "sweeps: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)", "controller + ring", "quadrature + accept", "-",
