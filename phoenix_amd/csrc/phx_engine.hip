@@ -990,7 +990,16 @@ int eval_nbc_ht3()
 }
 
 // ---- exchange-free parameter gradients of the prior branch (phx_mfma_batch.inc)
-constexpr int BATCH_FWD_MIN_ROWS = 1024;   // smaller batches: the pass-structured k1_eval_fwd has less launch overhead
+// Standalone evaluation of the RHS: the kernel chain (A -> R -> D) from this many rows up, the pass-structured k1_eval_fwd
+// below.  With the caller's packed weight images the chain's launches stage in one round trip and it wins at EVERY batch
+// size (round 4, C4: 16 rows 37 us against 77; 256: 64 / 85; 1000: 81 / 190); without images each of its two sweep
+// kernels pays the gather staging (25-40 us at C4) and small batches stay on the one-launch kernel.  PHX_BATCH_MIN_ROWS
+// overrides (tests run the small shapes on both).
+inline int batch_fwd_min_rows(bool have_images)
+{
+    if (const char *e = getenv("PHX_BATCH_MIN_ROWS")) return std::max(1, atoi(e));
+    return have_images ? 1 : 1024;
+}
 struct PlanBatch {
     D1 d;              // kernel A: gene tiles (NB blocks resident in LDS) x TG sweep groups
     size_t ldsA;
@@ -1399,7 +1408,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     }
     if (op == PHX_OP_RHS_FORWARD) {
         PlanBatch pb;
-        if (B >= BATCH_FWD_MIN_ROWS && plan_batch(N, H, B, &pb)) need = std::max(need, pb.total_fwd);
+        if (plan_batch(N, H, B, &pb)) need = std::max(need, pb.total_fwd);   // (whether the chain runs depends on the call's images)
         PlanEval pe;
         if (plan_eval(N, H, B, 8, &pe)) need = std::max(need, make_layout_eval(pe, false).total);
     }
@@ -1467,7 +1476,7 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
     hipStream_t st = (hipStream_t)stream;
     {   // large batches (the prior branch): exchange-free A -> R -> D chain (phx_mfma_batch.inc)
         PlanBatch pb;
-        if (B >= BATCH_FWD_MIN_ROWS && plan_batch(p->N, p->H, B, &pb)) {
+        if (plan_batch(p->N, p->H, B, &pb) && B >= batch_fwd_min_rows(batch_net(pb, p).wimg != nullptr)) {
             if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
             return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, y, out, prior_only, (char *)workspace, st)
                                 : launch_batch_forward<8>(pb, p, y, out, prior_only, (char *)workspace, st);

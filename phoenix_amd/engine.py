@@ -27,7 +27,7 @@ def _stream_ptr():
 
 _ws_bytes = {}
 _PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS", "PHX_FWD", "PHX_V3_NB",
-             "PHX_V3_HALF")
+             "PHX_V3_HALF", "PHX_BATCH_MIN_ROWS", "PHX_PGRAD_WGS", "PHX_PGRAD_G4")
 
 
 # phx_solve_opts.ws_keep: what the previous solve on a cached workspace was (plan key), so that the next identical one can
@@ -270,7 +270,7 @@ def rhs_vjp(p, y, cot, prior_only=False, want_grads=True, want_vjp_y=True, f_out
     return (vjp.reshape(y.shape) if want_vjp_y else None), grads
 
 
-PRIOR_MSE_MIN_ROWS = 1024   # BATCH_FWD_MIN_ROWS of the library: below it the workspace query does not cover the chain
+PRIOR_MSE_MIN_ROWS = 1024   # the fused loss head is for the large prior batches (train_insilico.py:134); smaller ones take the plain formula
 
 
 def prior_mse(p, X, target, keep_hidden=False):

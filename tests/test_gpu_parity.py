@@ -1072,8 +1072,8 @@ def test_prior_backward_from_saved_hidden_rows_equals_recomputation(pa, dev, N, 
                                    (11165, 40, 10000)])   # the last one: the prior batch of config C4 at its full size
 def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
     """prior_only_forward on a large batch and its parameter gradients (train_insilico.py:134-138): the exchange-free
-    MFMA chains of phx_mfma_batch.inc (forward from 1024 rows up, parameter gradients for any batch when the input
-    needs no gradient) and the pass-structured k1_eval_fwd below 1024 rows; H <= 48 and H = 120 tilings, a ragged
+    MFMA chains of phx_mfma_batch.inc (forward and parameter gradients for any batch when the input needs no gradient;
+    the pass-structured k1_eval_fwd: test_small_batch_evaluation_both_routes); H <= 48 and H = 120 tilings, a ragged
     last gene block, several partial-buffer chunks at breast scale."""
     p = rand_params(N, H, seed=3 * N + H, std=0.08)
     net, onet = make_net(pa, dev, p), onet_of(oracle, p)
@@ -1108,6 +1108,27 @@ def test_prior_branch_vs_oracle(pa, dev, oracle, N, H, K):
             assert np.max(np.abs(got2[k])) == 0, k
         else:
             assert relerr(got2[k], 0.01 * gr_ref[k]) < 4 * TOL_RHS, k
+
+
+@pytest.mark.parametrize("N,H,K", [(350, 40, 16), (1537, 24, 333), (600, 120, 70), (11165, 40, 200), (300, 131, 90)])
+def test_small_batch_evaluation_both_routes(pa, dev, oracle, monkeypatch, N, H, K):
+    """Standalone RHS evaluation of a small batch: with the packed weight images the library takes the kernel chain at
+    every batch size (round 4), without them -- or with PHX_BATCH_MIN_ROWS=1024 -- the pass-structured k1_eval_fwd.
+    Both routes against the oracle, full RHS and prior_only."""
+    p = rand_params(N, H, seed=7 * N + H, std=0.08)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    X = (np.random.RandomState(4).rand(K, 1, N) - 0.3).astype(np.float32)
+    Xt = torch.from_numpy(X).to(dev)
+    refs = {True: oracle.rhs(onet, X, prior_only=True), False: oracle.rhs(onet, X)}
+    outs = {}
+    for route in ("default", "1024"):
+        if route == "1024":
+            monkeypatch.setenv("PHX_BATCH_MIN_ROWS", "1024")
+        with torch.no_grad():
+            outs[route] = (net.prior_only_forward(torch.tensor(0.0), Xt).cpu().numpy(), net(torch.tensor(0.0), Xt).cpu().numpy())
+        assert relerr(outs[route][0], refs[True]) < TOL_RHS, route
+        assert relerr(outs[route][1], refs[False]) < TOL_RHS, route
+    assert relerr(outs["default"][0], outs["1024"][0]) < TOL_RHS
 
 
 def test_prior_branch_pass_structured_fallback(pa, dev, oracle, monkeypatch):
