@@ -1016,7 +1016,7 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
     if (cus <= 0 || force_v0()) return false;
     if (const char *e = getenv("PHX_PGRAD")) if (strcmp(e, "v1") == 0) return false;
     const int HC = (H + 127) / 128, Hc = (H + HC - 1) / HC;     // hidden chunks as in plan_v1: one chain per chunk
-    const int HT = Hc <= 48 ? 3 : 8;
+    const int HT = solve_ht(HC, Hc);   // the solve kernels' tiling: the caller's packed images fit (7 tiles for a 100-row chunk)
     const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4;   // the slot size of the packed images (stage_block_weights)
     if (blkbytes > LDS_BUDGET) return false;
     const int nblk = (N + 31) / 32;
@@ -1037,8 +1037,10 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
         const size_t nch = ((size_t)out->ntiles + cmax - 1) / cmax;
         return (int)(((size_t)out->ntiles + nch - 1) / nch);
     };
-    out->chunk_tiles = even_chunks(std::max<size_t>(64, ((size_t)128 << 20) / per_tile));
-    out->chunk_tiles2 = even_chunks(std::max<size_t>(64, ((size_t)256 << 20) / per_tile));
+    size_t chunk_min = 64;
+    if (const char *e = getenv("PHX_BATCH_CHUNK_MIN")) chunk_min = (size_t)std::max(1, atoi(e));
+    out->chunk_tiles = even_chunks(std::max<size_t>(chunk_min, ((size_t)128 << 20) / per_tile));
+    out->chunk_tiles2 = even_chunks(std::max<size_t>(chunk_min, ((size_t)256 << 20) / per_tile));
     const size_t part_bytes = std::max(per_tile * out->chunk_tiles, per_tile / 2 * out->chunk_tiles2);
     // kernel C: 64-gene slabs, four workgroups per CU.  (PHX_PGRAD_G4=8: 128-gene slabs, two per CU, half the A-operand
     // reads per MFMA -- measured slower at C4, 570 against 522 us: those reads are not what paces the kernel.)
@@ -1074,7 +1076,7 @@ bool plan_batch(int N, int H, int B, PlanBatch *out)
 
 
 // The Net of the batch kernels: with the caller's packed weight images when their tiling is the batch kernels' own
-// (phx_weight_image_bytes uses solve_ht: 7 hidden tiles for a chunked H <= 224, where plan_batch takes 8)
+// (both follow solve_ht since round 4; the check stays in case the two plans diverge again)
 // threads per workgroup of the sweep kernels of the batch chain (PHX_BATCH_WAVES: diagnostic, fewer waves than compiled for)
 template <int HT>
 inline int batch_threads(bool expansion = false)
@@ -1274,7 +1276,8 @@ int phx_prior_mse(const phx_params *p, const float *X, const float *target, int 
     if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, X, cot, 1, (char *)workspace, st, target, loss)
-                        : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss);
+                        : pb.d.HT == 7 ? launch_batch_forward<7>(pb, p, X, cot, 1, (char *)workspace, st, target, loss)
+                                       : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss);
 }
 
 size_t phx_prior_z_bytes(int N, int H, int B)
@@ -1293,7 +1296,8 @@ int phx_prior_mse_save(const phx_params *p, const float *X, const float *target,
     if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save)
-                        : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save);
+                        : pb.d.HT == 7 ? launch_batch_forward<7>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save)
+                                       : launch_batch_forward<8>(pb, p, X, cot, 1, (char *)workspace, st, target, loss, z_save);
 }
 
 int phx_prior_vjp_saved(const phx_params *p, const float *X, const float *cot, const float *z_saved, const phx_grads *grads,
@@ -1306,7 +1310,8 @@ int phx_prior_vjp_saved(const phx_params *p, const float *X, const float *cot, c
     if (workspace_bytes < pb.total) return PHX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     return pb.d.HT == 3 ? launch_batch_pgrad<3>(pb, p, X, cot, grads, (char *)workspace, st, z_saved)
-                        : launch_batch_pgrad<8>(pb, p, X, cot, grads, (char *)workspace, st, z_saved);
+                        : pb.d.HT == 7 ? launch_batch_pgrad<7>(pb, p, X, cot, grads, (char *)workspace, st, z_saved)
+                                       : launch_batch_pgrad<8>(pb, p, X, cot, grads, (char *)workspace, st, z_saved);
 }
 
 int phx_prior_targets(const int *colptr, const int *rowidx, const float *vals, const float *X, float *out, int K, int N,
@@ -1479,7 +1484,8 @@ int phx_rhs_forward(const phx_params *p, const float *y, float *out, int B, int 
         if (plan_batch(p->N, p->H, B, &pb) && B >= batch_fwd_min_rows(batch_net(pb, p).wimg != nullptr)) {
             if (workspace_bytes < pb.total_fwd) return PHX_ERR_WORKSPACE;
             return pb.d.HT == 3 ? launch_batch_forward<3>(pb, p, y, out, prior_only, (char *)workspace, st)
-                                : launch_batch_forward<8>(pb, p, y, out, prior_only, (char *)workspace, st);
+                                : pb.d.HT == 7 ? launch_batch_forward<7>(pb, p, y, out, prior_only, (char *)workspace, st)
+                                               : launch_batch_forward<8>(pb, p, y, out, prior_only, (char *)workspace, st);
         }
     }
     {   // v1: MFMA, weights staged once for all passes over the batch
@@ -1533,7 +1539,8 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
         if (plan_batch(p->N, p->H, B, &pb)) {       // exchange-free three-kernel path (phx_mfma_batch.inc)
             if (workspace_bytes < pb.total) return PHX_ERR_WORKSPACE;
             return pb.d.HT == 3 ? launch_batch_pgrad<3>(pb, p, y, cot, grads, (char *)workspace, st)
-                                : launch_batch_pgrad<8>(pb, p, y, cot, grads, (char *)workspace, st);
+                                : pb.d.HT == 7 ? launch_batch_pgrad<7>(pb, p, y, cot, grads, (char *)workspace, st)
+                                               : launch_batch_pgrad<8>(pb, p, y, cot, grads, (char *)workspace, st);
         }
         PlanEval pe;
         const int nbc3 = eval_nbc_ht3();
@@ -1576,7 +1583,8 @@ int phx_rhs_vjp(const phx_params *p, const float *y, const float *cot, float *vj
         if (plan_batch(p->N, p->H, B, &pb) && pb.d.NB <= 6) {
             if (workspace_bytes < pb.total_vjp) return PHX_ERR_WORKSPACE;
             return pb.d.HT == 3 ? launch_batch_vjp<3>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st)
-                                : launch_batch_vjp<8>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st);
+                                : pb.d.HT == 7 ? launch_batch_vjp<7>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st)
+                                               : launch_batch_vjp<8>(pb, p, y, cot, vjp_y, grads, f_out, prior_only, (char *)workspace, st);
         }
     }
     const Dims d = make_dims(p->N, p->H, B, 0, PHX_CTRL_PER_TRAJECTORY);
