@@ -275,8 +275,8 @@ PRIOR_MSE_MIN_ROWS = 1024   # the fused loss head is for the large prior batches
 
 def prior_mse(p, X, target, keep_hidden=False):
     """fused mean((prior_only_forward(X) - target)^2) and its cotangent; returns (loss [1], cot like X) -- with
-    `keep_hidden` (loss, cot, z): z = the reduced hidden rows of the forward chain for `prior_vjp_saved`, or None where
-    the library has no such path (H > 128) -- or None when the engine cannot plan the batch chain for this shape
+    `keep_hidden` (loss, cot, z): z = what `prior_vjp_saved` needs of the hidden layer (since ABI 7 the four sections
+    du | dv | z_u | z_p of every row, formed with THIS cotangent), or None where the library has no such path (H > 128) -- or None when the engine cannot plan the batch chain for this shape
     (caller falls back to the unfused formula)."""
     _require_gpu(X, "X")
     _require_gpu(target, "target")
@@ -304,9 +304,9 @@ def prior_mse(p, X, target, keep_hidden=False):
 
 
 def prior_vjp_saved(p, X, cot, z):
-    """parameter gradients of sum(cot * prior_only_forward(X)) from the hidden rows `z` that `prior_mse(...,
-    keep_hidden=True)` kept (phx_prior_vjp_saved): what rhs_vjp(prior_only=True, want_vjp_y=False) returns, without
-    recomputing the hidden layer."""
+    """parameter gradients of sum(cot * prior_only_forward(X)) from the hidden sections `z` that `prior_mse(...,
+    keep_hidden=True)` kept (phx_prior_vjp_saved): what rhs_vjp(prior_only=True, want_vjp_y=False) returns, with the
+    gradient contraction alone.  `cot` must be the cotangent that same call returned (z holds du, dv formed with it)."""
     _require_gpu(X, "X")
     _require_gpu(cot, "cot")
     x2 = X.detach().reshape(-1, p.N).contiguous()
