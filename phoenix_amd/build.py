@@ -13,12 +13,18 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libphoenix_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-# Per-unit flags (none at present).  Round 3 suspected inter-procedural register allocation behind the "trajectories
+# Per-unit flags.  phx_fwd3.hip: the iterative-ILP machine scheduler (round 4, same-device A/B: forward launch 0.2413 ->
+# 0.2394 ms; the same flag makes k1_solve_adj3 slower, 0.536 -> 0.55 ms, so that unit keeps the default).  Round 3 suspected inter-procedural register allocation behind the "trajectories
 # 12..15 take thousands of steps" signature and round 4 first built the third-generation kernels with
 # `-mllvm -enable-ipra=false`; the cause turned out to be a gfx950 store-data hazard the compiler does not cover
 # (tools/membench/store_war.hip), fixed in the source (phx_mfma_v3common.inc: bstore_guard) and checked statically after
 # every build by tools/check_store_hazard.py (tests/test_abi_cpu.py runs it on the listings build() leaves in _obj/).
-UNIT_FLAGS = {}
+UNIT_FLAGS = {"phx_fwd3.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+# Diagnostic build (PHX_PROF=2: per-block timers inside the sweeps of the third-generation kernels): the marks are compiled
+# in only with -DPHX_PROF_BLOCKS -- as run-time branches they split the sweep body into several scheduling regions and cost
+# 2.3 % (forward) / 1.5 % (backward) of the launch (round 4).  build_prof() writes libphoenix_prof.so next to the library.
+PROF_LIB = os.path.join(HERE, "libphoenix_prof.so")
+PROF_UNITS = ("phx_fwd3.hip", "phx_adj3.hip")
 # Units whose device assembly is also written to csrc/_obj/<unit>.s: every kernel that stores through buffer resources
 # (the store-data hazard is checked on these listings, tools/check_store_hazard.py)
 LISTINGS = ("phx_fwd3.hip", "phx_adj3.hip")
@@ -89,6 +95,35 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_prof(verbose=False):
+    """libphoenix_prof.so: the library with the per-block timer marks compiled into the third-generation kernels
+    (tools/prof_segments.py loads it for PHX_PROF=2); the other units are taken from the regular build."""
+    build()
+    stale = not os.path.exists(PROF_LIB) or any(os.path.getmtime(p) > os.path.getmtime(PROF_LIB) for p in sources() + deps())
+    if not stale:
+        return PROF_LIB
+    procs, objs = [], []
+    for s in sources():
+        b = os.path.basename(s)
+        if b in PROF_UNITS:
+            o = os.path.join(OBJ, b[:-4] + ".prof.o")
+            cmd = [hipcc()] + FLAGS + UNIT_FLAGS.get(b, []) + ["-DPHX_PROF_BLOCKS", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+            objs.append(o)
+        else:
+            objs.append(_obj_of(s))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF_LIB] + objs, cwd=CSRC)
+    return PROF_LIB
+
+
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--prof" in sys.argv:
+        print(build_prof(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

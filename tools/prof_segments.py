@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: per-segment time of the v1 persistent kernels (PHX_PROF=1), averaged over workgroups.
-usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj] [trajectories]"""
+usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj] [trajectories]
+PHX_PROF=2 (per-block timers inside the sweeps of the third-generation kernels) needs the diagnostic build of the library
+(the marks are compiled out of the regular one: they cost 1.5-2.3 % of a launch): `python -m phoenix_amd.build --prof`
+here, or it is built on first use; this script then loads libphoenix_prof.so."""
 import ctypes as C
 import os
 import sys
@@ -10,6 +13,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PHX_PROF", "1")
+if os.environ["PHX_PROF"] == "2" and "PHX_LIB" not in os.environ:
+    from phoenix_amd import build as _build
+    os.environ["PHX_DIAG"] = "1"
+    os.environ["PHX_LIB"] = _build.build_prof()
 import bench  # noqa: E402
 from phoenix_amd import _lib, engine  # noqa: E402
 
