@@ -14,12 +14,14 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libphoenix_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Per-unit flags.  phx_fwd3.hip: the iterative-ILP machine scheduler (round 4, same-device A/B: forward launch 0.2413 ->
-# 0.2394 ms; the same flag makes k1_solve_adj3 slower, 0.536 -> 0.55 ms, so that unit keeps the default).  Round 3 suspected inter-procedural register allocation behind the "trajectories
+# 0.2394 ms; the same flag makes k1_solve_adj3 slower, 0.536 -> 0.55 ms, so that unit keeps the default) and phx_adj2.hip
+# (C3 yeast backward 7.28 -> 6.86 ms, C2 in-silico 0.5415 -> 0.5367 ms).  Round 3 suspected inter-procedural register allocation behind the "trajectories
 # 12..15 take thousands of steps" signature and round 4 first built the third-generation kernels with
 # `-mllvm -enable-ipra=false`; the cause turned out to be a gfx950 store-data hazard the compiler does not cover
 # (tools/membench/store_war.hip), fixed in the source (phx_mfma_v3common.inc: bstore_guard) and checked statically after
 # every build by tools/check_store_hazard.py (tests/test_abi_cpu.py runs it on the listings build() leaves in _obj/).
-UNIT_FLAGS = {"phx_fwd3.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+UNIT_FLAGS = {"phx_fwd3.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+              "phx_adj2.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 # Diagnostic build (PHX_PROF=2: per-block timers inside the sweeps of the third-generation kernels): the marks are compiled
 # in only with -DPHX_PROF_BLOCKS -- as run-time branches they split the sweep body into several scheduling regions and cost
 # 2.3 % (forward) / 1.5 % (backward) of the launch (round 4).  build_prof() writes libphoenix_prof.so next to the library.
