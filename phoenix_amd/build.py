@@ -18,13 +18,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # (C3 yeast backward 7.28 -> 6.86 ms, C2 in-silico 0.5415 -> 0.5367 ms).  phx_adj3.hip was also tried with max-ilp,
 # max-memory-clause, iterative-minreg, iterative-maxocc (all slower: 0.545 ... 0.580 ms), -fno-slp-vectorize, -O2 and the
 # schedule-metric-bias / relaxed-occupancy knobs (no difference); phx_engine.hip with iterative-ilp crashes this clang
-# (segmentation fault in the backend), so it keeps the default.  Round 3 suspected inter-procedural register allocation behind the "trajectories
+# (segmentation fault in the backend), so it keeps the default -- its first-generation solve kernels were moved to
+# phx_v1.hip for the flag (C5 step 47.9 -> 47.5 ms, C2 forward 0.213 -> 0.205 ms; phx_engine.hip now compiles in 40 s).  Round 3 suspected inter-procedural register allocation behind the "trajectories
 # 12..15 take thousands of steps" signature and round 4 first built the third-generation kernels with
 # `-mllvm -enable-ipra=false`; the cause turned out to be a gfx950 store-data hazard the compiler does not cover
 # (tools/membench/store_war.hip), fixed in the source (phx_mfma_v3common.inc: bstore_guard) and checked statically after
 # every build by tools/check_store_hazard.py (tests/test_abi_cpu.py runs it on the listings build() leaves in _obj/).
 UNIT_FLAGS = {"phx_fwd3.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
-              "phx_adj2.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
+              "phx_adj2.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+              "phx_v1.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 # Diagnostic build (PHX_PROF=2: per-block timers inside the sweeps of the third-generation kernels): the marks are compiled
 # in only with -DPHX_PROF_BLOCKS -- as run-time branches they split the sweep body into several scheduling regions and cost
 # 2.3 % (forward) / 1.5 % (backward) of the launch (round 4).  build_prof() writes libphoenix_prof.so next to the library.

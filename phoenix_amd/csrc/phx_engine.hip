@@ -752,6 +752,23 @@ __global__ __launch_bounds__(NT) void k_solve_fwd(Net net, Dims d, WS w, SolveCf
 #include "phx_mfma_common.inc"
 #include "phx_mfma_fwd.inc"
 #include "phx_mfma_adj.inc"
+// the v1 solve kernels are instantiated in phx_v1.hip (own compiler flags); here they are only launched
+#define PHX_V1_FWD(HT, MAXT, CH)                                                                                        \
+    extern template __global__ void phxk::k1_solve_fwd<HT, MAXT, CH>(Net, D1, W1, SolveCfg, const float *, const double *, \
+                                                                    float *, int *, int *, int *)
+#define PHX_V1_ADJ(HT, MAXT, CH)                                                                                        \
+    extern template __global__ void phxk::k1_solve_adj<HT, MAXT, CH>(Net, D1, W1, SolveCfg, const double *, const float *, \
+                                                                    const float *, float *, int *, int *, int *, int,     \
+                                                                    long long)
+PHX_V1_FWD(7, 256, true);
+PHX_V1_FWD(8, 256, true);
+PHX_V1_FWD(3, 512, false);
+PHX_V1_FWD(3, 256, false);
+PHX_V1_FWD(8, 256, false);
+PHX_V1_ADJ(7, 256, true);
+PHX_V1_ADJ(8, 256, true);
+PHX_V1_ADJ(3, 256, false);
+PHX_V1_ADJ(8, 256, false);
 #include "phx_mfma_eval.inc"
 #include "phx_mfma_batch.inc"
 #include "phx_prior.inc"

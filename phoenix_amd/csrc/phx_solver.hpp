@@ -23,6 +23,41 @@ struct SolveCfg {
     long long max_steps;
 };
 
+// launch geometry (D1) and workspace pointers (W1) of the v1 / v2 / v3 MFMA kernels (phx_mfma_common.inc)
+struct D1 {
+    int N, H, B, T;
+    int HT;    // hidden tiles of 16 rows (H <= 16*HT)
+    int NB;    // gene blocks per workgroup
+    int NW;    // waves per workgroup
+    int TPW;   // trajectory tiles per wave
+    int G;     // gene tiles  (workgroups per batch group)
+    int TG;    // batch groups
+    int nblk;  // gene blocks in total
+    int ntg;   // trajectory tiles per group = NW*TPW
+    int Bt;    // trajectories per group = 16*ntg
+    int nvec;  // private state vectors per workgroup
+    long long BN;
+    int HC;    // hidden-row chunks (1: all weights of the gene tile stay LDS resident; >1: H > 128, the chunks of
+    int Hc;    // Hc rows are re-staged per evaluation: f = sum over chunks, see DESIGN.md "wide hidden layers")
+    int Bcall; // > 0: the batch is `TG` independent odeint calls of Bcall trajectories (shared control per call), batch
+               // group g = call g, rows [g*Bcall, (g+1)*Bcall) of the caller's arrays;  0: groups are Bt consecutive rows
+    long long cntN;   // elements under one shared-control norm (rows of one call x N)
+};
+
+struct W1 {
+    unsigned long long *cnt;   // [TG] monotonically increasing group counters (zeroed per launch)
+    unsigned int *abort_flag;
+    unsigned long long *part;  // [TG][G][R][64] granules {tag<<32 | f32}: per-workgroup partial rows
+    unsigned long long *zbuf;  // [slots][TG][R][64] granules: reduced rows (hidden vector, then norm rows)
+    float *scratch;            // [TG*G][nvec][ntg*NB][64][8]     workgroup-private state tiles
+    float *dtheta;             // [TG][PP] parameter-gradient partials (adjoint)
+    unsigned long long *prof;  // [TG*G][16] optional per-workgroup segment timers (PHX_PROF=1), else null
+    const float *wimg;         // chunked hidden layer: pre-packed LDS images [gene block][chunk][blk_floats_ch]
+    float *hq;                 // k1_solve_adj2: wave-private transposed hidden rows [WG][8][TPW][7][2HT][64] float4
+    unsigned long long *part1, *zbuf1;   // third-generation kernels: the second set of exchange buffers (xset_begin)
+    int prof_level;            // k1_solve_fwd3: PHX_PROF level (2: per-block timers inside the sweeps)
+};
+
 }  // namespace phxt
 using namespace phxt;
 
