@@ -29,9 +29,9 @@ UNIT_FLAGS = {"phx_fwd3.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
               "phx_v1.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 # Diagnostic build (PHX_PROF=2: per-block timers inside the sweeps of the third-generation kernels): the marks are compiled
 # in only with -DPHX_PROF_BLOCKS -- as run-time branches they split the sweep body into several scheduling regions and cost
-# 2.3 % (forward) / 1.5 % (backward) of the launch (round 4).  build_prof() writes libphoenix_prof.so next to the library.
+# 2.3 % (forward) / 1.5 % (backward) of the third-generation launches and 3.3 % of the second backward kernel at C3 (round 4).  build_prof() writes libphoenix_prof.so next to the library.
 PROF_LIB = os.path.join(HERE, "libphoenix_prof.so")
-PROF_UNITS = ("phx_fwd3.hip", "phx_adj3.hip")
+PROF_UNITS = ("phx_fwd3.hip", "phx_adj3.hip", "phx_adj2.hip")
 # Units whose device assembly is also written to csrc/_obj/<unit>.s: every kernel that stores through buffer resources
 # (the store-data hazard is checked on these listings, tools/check_store_hazard.py)
 LISTINGS = ("phx_fwd3.hip", "phx_adj3.hip")
@@ -102,9 +102,13 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_prof(verbose=False):
-    """libphoenix_prof.so: the library with the per-block timer marks compiled into the third-generation kernels
-    (tools/prof_segments.py loads it for PHX_PROF=2); the other units are taken from the regular build."""
+def build_prof(verbose=False, check_stale=True):
+    """libphoenix_prof.so: the library with the per-block timer marks compiled into the second / third-generation kernels
+    (tools/prof_segments.py loads it for PHX_PROF=2); the other units are taken from the regular build.
+    check_stale=False: an existing file is used as it is (on a GPU box the snapshot's modification times are not those
+    of the build container, and a rebuild there costs four minutes of GPU time)."""
+    if os.path.exists(PROF_LIB) and not check_stale:
+        return PROF_LIB
     build()
     stale = not os.path.exists(PROF_LIB) or any(os.path.getmtime(p) > os.path.getmtime(PROF_LIB) for p in sources() + deps())
     if not stale:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-segment time of the v1 persistent kernels (PHX_PROF=1), averaged over workgroups.
 usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj] [trajectories]
-PHX_PROF=2 (per-block timers inside the sweeps of the third-generation kernels) needs the diagnostic build of the library
+PHX_PROF=2 (per-block timers inside the sweeps of the second / third-generation kernels) needs the diagnostic build of the library
 (the marks are compiled out of the regular one: they cost 1.5-2.3 % of a launch): `python -m phoenix_amd.build --prof`
 here, or it is built on first use; this script then loads libphoenix_prof.so."""
 import ctypes as C
@@ -16,7 +16,7 @@ os.environ.setdefault("PHX_PROF", "1")
 if os.environ["PHX_PROF"] == "2" and "PHX_LIB" not in os.environ:
     from phoenix_amd import build as _build
     os.environ["PHX_DIAG"] = "1"
-    os.environ["PHX_LIB"] = _build.build_prof()
+    os.environ["PHX_LIB"] = _build.build_prof(check_stale=False)   # build it here first: python -m phoenix_amd.build --prof
 import bench  # noqa: E402
 from phoenix_amd import _lib, engine  # noqa: E402
 
@@ -39,6 +39,10 @@ op = _lib.OP_ODEINT if which == "fwd" else _lib.OP_ADJOINT
 rc = lib.phx_debug_profile_region(op, N, H, B, T, _lib.CTRL_PER_TRAJECTORY, C.byref(off), C.byref(nwg), plan)
 assert rc == 0, "no v1 plan for this shape"
 print("plan NW=%d TPW=%d NB=%d G=%d TG=%d HT=%d  workgroups=%d" % (*plan, nwg.value))
+_k = lib.phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS[wl["method"]]) if which == "adj" else 0
+_third = _k == 3 or (which == "fwd" and wl["method"] == "dopri5" and H <= 48 and os.environ.get("PHX_FWD") != "v1")
+if os.environ["PHX_PROF"] == "2" and not _third:
+    os.environ["PHX_PROF"] = "1"   # the second / first-generation kernels know one level; the diagnostic build stays loaded
 G = torch.randn(T, B, N, device=dev) / (B * N)
 for rep in range(3):
     sol, st, nfe, ns = engine.solve_forward(p, y2, t64, wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
