@@ -472,15 +472,24 @@ def main(args):
         for _ in range(3):
             win2.append(timed_region(step2, sync_all, args.steps, engine, use_dist, device) / args.steps * 1e3)
         engine.set_status_mode("immediate")
-        # dopri5 takes the same number of evaluations per trajectory whichever rank integrates it (per-trajectory
-        # control), so the sharded batch's evaluation count is the weak problem's per-trajectory average x 256
-        evals2 = whole_job((nfe_fwd + nfe_aug) / B * B2 * N)
+        # the sharded problem's OWN evaluation counts: one more solve of this rank's shard through the engine entry
+        # points (statistics outputs), summed over the ranks
+        p2 = engine.Params(net2.net_sums.linear_out.weight, net2.net_sums.linear_out.bias, net2.net_prods.linear_out.weight,
+                           net2.net_prods.linear_out.bias, net2.net_alpha_combine.linear_out.weight, net2.gene_multipliers)
+        t64_2 = t2.double().contiguous()
+        sol2, st_f2, nfe_f2, _ = engine.solve_forward(p2, y02.reshape(B2, N).contiguous(), t64_2, wl["method"],
+                                                      _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+        _, _, st_b2, nfe_b2, _ = engine.solve_adjoint(p2, t64_2, sol2, G2.reshape(T, B2, N).contiguous(), wl["method"],
+                                                      _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+        torch.cuda.synchronize()
+        assert int(st_f2.max()) == 0 and int(st_b2.max()) == 0
+        evals2 = whole_job((int(nfe_f2.sum().item()) + int(nfe_b2.sum().item())) * N)
         other = {"scaling": "strong", "trajectories_total": Bw, "trajectories_per_gpu": B2,
                  "ms_per_step": el2 / args.steps * 1e3, "value": evals2 * args.steps / el2,
                  "window_ms_per_step": win2,
                  "note": "the ONE %d-trajectory batch of BASELINE.json config 4 sharded over the %d ranks, loss "
                          "normalised by the global batch, grouped gradient all-reduce; evaluations counted from the "
-                         "per-trajectory NFE of the weak problem's trajectories (same distribution)" % (Bw, world)}
+                         "sharded problem's own NFE outputs, summed over the ranks" % (Bw, world)}
 
     if rank == 0:
         P = 4 * H * N + 2 * H + N
@@ -493,9 +502,9 @@ def main(args):
         flop_fwd = (nfe_fwd / B) * 8.0 * B * N * H
         flop_adj = (nfe_aug / B) * 24.0 * B * N * H
         mid = _lib.METHODS[wl["method"]]
-        adj_kernel = {0: "k_solve_adj", 1: "k1_solve_adj", 2: "k1_solve_adj2", 3: "k1_solve_adj3"}[
+        adj_kernel = {0: "k_solve_adj", 1: "k1_solve_adj", 2: "k1_solve_adj2", 3: "k1_solve_adj3", 4: "k1_solve_adj3c"}[
             _lib.load().phx_debug_adjoint_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid)]
-        fwd_kernel = {0: "k_solve_fwd", 1: "k1_solve_fwd", 3: "k1_solve_fwd3"}[
+        fwd_kernel = {0: "k_solve_fwd", 1: "k1_solve_fwd", 3: "k1_solve_fwd3", 4: "k1_solve_fwd3c"}[
             _lib.load().phx_debug_forward_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid)]
         dom = adj_kernel if adj_ms_avg >= fwd_ms_avg else fwd_kernel   # key into the PMC summary
         alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == adj_kernel else (alg_fwd, flop_fwd, fwd_ms_avg)
@@ -510,17 +519,26 @@ def main(args):
         # --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B/lane streams)
         # (the counters cannot be read while the bench runs un-profiled: the figure is the committed summary of the
         # profiled run of this same command, regenerated by tools/collect_profiles.sh)
+        # Provenance: the summary names the library it was collected on (sha256 of libphoenix_hip.so, written by
+        # tools/summarize_profiles.py); a summary of ANOTHER build is not this run's traffic -> `traffic: null` + a note.
         traffic, pmc_file, pmc_note = None, None, None
-        for tag in ("r4", "r3", "r2"):
+        import hashlib
+        lib_sha = hashlib.sha256(open(_lib.lib_path(), "rb").read()).hexdigest()
+        for tag in ("r5", "r4", "r3", "r2"):
             cand = os.path.join(ROOT, "profiles", "%s_%s_pmc_hbm.json" % (tag, args.workload))
             if os.path.exists(cand):
                 try:
                     pmc = json.load(open(cand))
+                    if pmc.get("library_sha256") != lib_sha:
+                        pmc_note = ("%s was collected on another build of libphoenix_hip.so (sha256 %s, running %s): traffic "
+                                    "not reported" % (os.path.basename(cand), str(pmc.get("library_sha256"))[:12], lib_sha[:12]))
+                        break
                     traffic = (2.0 * pmc["FETCH_SIZE_KB_per_launch"][dom] + pmc["WRITE_SIZE_KB_per_launch"][dom]) * 1024.0
                     pmc_file = os.path.relpath(cand, ROOT)
                     break
                 except Exception as exc:   # noqa: BLE001
                     traffic, pmc_note = None, "%s: %r" % (os.path.basename(cand), exc)
+                    break
         roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
                     "achieved": tflops if mfma_bound else achieved,
                     "peak": PEAK_MFMA_F32 if mfma_bound else PEAK_HBM,
@@ -532,8 +550,10 @@ def main(args):
                                  "frac": tflops / PEAK_MFMA_F32, "algorithmic_flop_per_launch": flop},
                     "traffic": traffic,
                     "measured_hbm_GBps": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
-                    "traffic_source": ("%s (2*FETCH_SIZE + WRITE_SIZE of a separate profiled run of this command; not "
-                                       "measured in this run)" % pmc_file) if traffic else pmc_note,
+                    "traffic_source": ("%s (2*FETCH_SIZE + WRITE_SIZE of a separate profiled run of this command on this "
+                                       "same library build, sha256 %s; not measured in this run)"
+                                       % (pmc_file, lib_sha[:12])) if traffic else pmc_note,
+                    "library_sha256": lib_sha,
                     "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
                     "forward": {"kernel": fwd_kernel, "launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
                                 "TFLOPs": flop_fwd / (fwd_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_fwd / B},
@@ -545,6 +565,9 @@ def main(args):
             "unit": "gene*trajectory RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": headline,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "step_definition": "odeint_adjoint forward solve + torch.autograd.backward(sol, dL/dsol) (the backward solve is "
+                               "entered with the loss cotangent; no loss-head kernels) + parameter re-layout + gradient "
+                               "reduction (+ all-reduce); since round 4 (rounds 1-3 timed (sol * G).sum().backward())",
             "config": {"workload": wl["desc"], "genes": N, "hidden": H, "trajectories_per_gpu": B,
                        "method": wl["method"], "rtol": 1e-7, "atol": 1e-9, "time_points": wl["t"],
                        "parallelism": "trajectory-sharded x%d, grouped gradient all-reduce" % world,
@@ -621,6 +644,49 @@ def main(args):
                         "ms_per_step_status_immediate": (time.perf_counter() - t0) / 20 * 1e3})
             except Exception as exc:   # noqa: BLE001
                 out["extra"]["error"] = repr(exc)[:200]
+            # The reference's OWN batch size (config_breast.cfg:6 `batch_size = 17`, config_yeast.cfg:6 4, config_BCell.cfg:6 2;
+            # loop train_insilico.py:128-130): the same step on that many trajectories, per-sample control.  HBM / latency
+            # bound there (AI = 8BNH / (4P + 8BN) is ~7 flop/B forward at B = 17, below the 19.7 ridge).
+            try:
+                Bref = {"breast": 17, "yeast": 4, "bcell": 2, "insilico": 4}[args.workload]
+                if not use_dist and Bref < B:
+                    engine.set_status_mode(args.status)
+                    try:
+                        ys, ts_, Gs = y0[:Bref].contiguous(), t[:Bref].contiguous(), (G[:, :Bref] * (B / Bref)).contiguous()
+                        for _ in range(20):
+                            one_step(net, ys, ts_, Gs, wl["method"], 1)
+                        engine.check_pending_status(wait=True)
+                        torch.cuda.synchronize()
+                        reps = 50
+                        t0 = time.perf_counter()
+                        for _ in range(reps):
+                            one_step(net, ys, ts_, Gs, wl["method"], 1)
+                        engine.check_pending_status(wait=True)
+                        torch.cuda.synchronize()
+                        ms_ref = (time.perf_counter() - t0) / reps * 1e3
+                    finally:
+                        engine.set_status_mode("immediate")
+                    solr, str_, nfr, _ = engine.solve_forward(p, ys.reshape(Bref, N).contiguous(), ts_.double().contiguous(),
+                                                              wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+                    _, _, stb_, nbr, _ = engine.solve_adjoint(p, ts_.double().contiguous(), solr,
+                                                              Gs.reshape(T, Bref, N).contiguous(), wl["method"],
+                                                              _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
+                    torch.cuda.synchronize()
+                    nf_r, nb_r = int(nfr.sum().item()), int(nbr.sum().item())
+                    bytes_r = (nf_r / Bref) * (4 * P + 8 * Bref * N) + (nb_r / Bref) * (8 * P + 16 * Bref * N)
+                    flop_r = (nf_r / Bref) * 8.0 * Bref * N * H + (nb_r / Bref) * 24.0 * Bref * N * H
+                    out["extra"]["reference_batch"] = {
+                        "trajectories": Bref, "control": "per-sample", "ms_per_step": ms_ref,
+                        "value": (nf_r + nb_r) * N / (ms_ref * 1e-3), "unit": "gene*trajectory RHS evals/s",
+                        "nfe_forward": nf_r, "nfe_augmented": nb_r,
+                        "roofline": {"bound": "hbm", "achieved": bytes_r / (ms_ref * 1e-3) / 1e9, "peak": PEAK_HBM,
+                                     "unit": "GB/s", "frac": bytes_r / (ms_ref * 1e-3) / 1e9 / PEAK_HBM,
+                                     "arithmetic_intensity_flop_per_byte": flop_r / bytes_r,
+                                     "algorithmic_bytes_per_step": bytes_r, "traffic": None},
+                        "note": "the reference's own batch_size for this data set (its config file), whole step wall time "
+                                "(two solve launches + layout + gradient reduction), deferred status"}
+            except Exception as exc:   # noqa: BLE001
+                out["extra"]["reference_batch_error"] = repr(exc)[:200]
         if world == 1 and not args.no_cpu_baseline:
             # both shapes BASELINE.md section 3 names; speed-ups are quoted against the stronger one
             loop = cpu_baseline(wl, net, y0, t, G)

@@ -34,7 +34,7 @@ PROF_LIB = os.path.join(HERE, "libphoenix_prof.so")
 PROF_UNITS = ("phx_fwd3.hip", "phx_adj3.hip", "phx_adj2.hip")
 # Units whose device assembly is also written to csrc/_obj/<unit>.s: every kernel that stores through buffer resources
 # (the store-data hazard is checked on these listings, tools/check_store_hazard.py)
-LISTINGS = ("phx_fwd3.hip", "phx_adj3.hip")
+LISTINGS = ("phx_fwd3.hip", "phx_adj3.hip", "phx_fwd3c.hip", "phx_adj3c.hip")
 
 
 def sources():
@@ -62,6 +62,22 @@ def listing_of(src):
     return os.path.join(OBJ, os.path.basename(src)[:-4] + ".s")
 
 
+def _keep_listing(src, dst, stem=None):
+    """moves the gfx950 assembly `-save-temps=obj` left beside the object to `dst` and deletes the other temporaries"""
+    # (the temporaries are named after the SOURCE file, whatever the object is called)
+    stem = os.path.basename(src)[:-4]
+    found = False
+    for f in (glob.glob(os.path.join(OBJ, stem + "-hip-*")) + glob.glob(os.path.join(OBJ, stem + "-host-*")) +
+              glob.glob(os.path.join(OBJ, stem + ".hip-hip-*"))):
+        if f.endswith("gfx950.s"):
+            os.replace(f, dst)
+            found = True
+        else:
+            os.remove(f)
+    if not found:
+        raise RuntimeError("no device assembly was kept for %s" % src)
+
+
 def _stale(src):
     o = _obj_of(src)
     if not os.path.exists(o) or (os.path.basename(src) in LISTINGS and not os.path.exists(listing_of(src))):
@@ -85,16 +101,19 @@ def build(force=False, verbose=False):
     procs = []
     for s in todo:
         cmd = [hipcc()] + FLAGS + UNIT_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", _obj_of(s)]
+        # the checked listing is the device assembly of THIS invocation (-save-temps keeps what the object is assembled
+        # from), not of a second compile whose flags could drift from the first
+        if os.path.basename(s) in LISTINGS:
+            cmd.insert(1, "-save-temps=obj")
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
-    for s in todo:
-        if os.path.basename(s) in LISTINGS:
-            cmd = [hipcc()] + FLAGS + UNIT_FLAGS.get(os.path.basename(s), []) + ["-S", "--cuda-device-only", s, "-o", listing_of(s)]
-            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.DEVNULL)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    for s in todo:
+        if os.path.basename(s) in LISTINGS:
+            _keep_listing(s, listing_of(s))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj_of(s) for s in sources()]
     if verbose:
         print(" ".join(cmd))
@@ -119,6 +138,8 @@ def build_prof(verbose=False, check_stale=True):
         if b in PROF_UNITS:
             o = os.path.join(OBJ, b[:-4] + ".prof.o")
             cmd = [hipcc()] + FLAGS + UNIT_FLAGS.get(b, []) + ["-DPHX_PROF_BLOCKS", "-c", s, "-o", o]
+            if b in LISTINGS:
+                cmd.insert(1, "-save-temps=obj")
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
@@ -128,8 +149,16 @@ def build_prof(verbose=False, check_stale=True):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+    for s in sources():
+        b = os.path.basename(s)
+        if b in PROF_UNITS and b in LISTINGS:      # the diagnostic build's listings are checked too (prof_listings())
+            _keep_listing(s, os.path.join(OBJ, b[:-4] + ".prof.s"))
     subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF_LIB] + objs, cwd=CSRC)
     return PROF_LIB
+
+
+def prof_listings():
+    return [os.path.join(OBJ, b[:-4] + ".prof.s") for b in PROF_UNITS if b in LISTINGS]
 
 
 if __name__ == "__main__":

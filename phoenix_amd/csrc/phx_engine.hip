@@ -1384,7 +1384,9 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
     if (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT) return PHX_ERR_BAD_ARG;
     const bool adj = op == PHX_OP_ADJOINT;
     if (!adj && fwd3_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
+    if (!adj && fwd3c_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (adj && adj3_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
+    if (adj && adj3c_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (adj && adj2_profile_region(N, H, B, T, control, offset, n_workgroups, plan) == PHX_OK) return PHX_OK;
     if (!plan_v1(N, H, B, T, control, adj ? NVEC_ADJ : NVEC_FWD, 2, adj ? ADJ_LDS_EXTRA : 0, &d1, adj ? 40 : 0,
                  adj ? ADJ_NW_CAP : 8))
@@ -1404,6 +1406,7 @@ int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control)
 int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int method)
 {
     if (adj3_chunk(N, H, B, T, control, method) > 0) return 3;
+    if (adj3c_chunk(N, H, B, T, control, method) > 0) return 4;   // third generation, chunked hidden layer (H > 48)
     if (adj2_chunk(N, H, B, T, control) > 0) return 2;
     return pick_chunk_v1(N, H, B, T, control, true) > 0 ? 1 : 0;
 }
@@ -1411,6 +1414,7 @@ int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int meth
 int phx_debug_forward_kernel_m(int N, int H, int B, int T, int control, int method)
 {
     if (fwd3_chunk(N, H, B, T, control, method) > 0) return 3;
+    if (fwd3c_chunk(N, H, B, T, control, method) > 0) return 4;   // third generation, chunked hidden layer (H > 48)
     return pick_chunk_v1(N, H, B, T, control, false) > 0 ? 1 : 0;
 }
 
@@ -1421,6 +1425,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     size_t need = make_layout(d, op).total;
     if (op == PHX_OP_ODEINT) {
         need = std::max(need, fwd3_workspace_bytes(N, H, B, T));
+        need = std::max(need, fwd3c_workspace_bytes(N, H, B, T));
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl) {
             const int bc = pick_chunk_v1(N, H, B, T, ctl, false);
@@ -1444,6 +1449,7 @@ size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
     if (op == PHX_OP_ADJOINT) {
         need = std::max(need, adj2_workspace_bytes(N, H, B, T));
         need = std::max(need, adj3_workspace_bytes(N, H, B, T));
+        need = std::max(need, adj3c_workspace_bytes(N, H, B, T));
         D1 d1;
         for (int ctl = 0; ctl < 2; ++ctl) {
             const int bc = pick_chunk_v1(N, H, B, T, ctl, true);
@@ -1646,6 +1652,9 @@ int phx_odeint(const phx_params *p, const float *y0_all, const double *t_all, in
     // third-generation forward kernel (dopri5, narrow hidden layer; phx_fwd3.hip)
     if (!Bcall && fwd3_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
         return fwd3_run(p, y0_all, t_all, B, T, o, sol_all, status_all, nfe_all, nsteps_all, workspace, workspace_bytes, st);
+    // ... and its hidden-chunked form for wide hidden layers (H > 48: the yeast and B-cell shapes; phx_fwd3c.hip)
+    if (!Bcall && fwd3c_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
+        return fwd3c_run(p, y0_all, t_all, B, T, o, sol_all, status_all, nfe_all, nsteps_all, workspace, workspace_bytes, st);
     // v1: MFMA kernels with LDS-resident weights, when the shape fits (large batches: in chunks)
     const int chunk_f = Bcall ? pick_calls_v1(p->N, p->H, B, T, calls) * Bcall : pick_chunk_v1(p->N, p->H, B, T, o->control, false);
     if (Bcall && chunk_f == 0) return PHX_ERR_BAD_ARG;
@@ -1739,6 +1748,10 @@ int phx_odeint_adjoint_backward(const phx_params *p, const double *t_all, int B,
     if (adj3_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
         return adj3_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,
                         workspace, workspace_bytes, st);
+    // ... and its hidden-chunked form for wide hidden layers (H > 48: the yeast and B-cell shapes; phx_adj3c.hip)
+    if (adj3c_chunk(p->N, p->H, B, T, o->control, o->method) > 0)
+        return adj3c_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,
+                         workspace, workspace_bytes, st);
     // second-generation MFMA kernel (wave pairs, fused sweeps): hidden layers that stay LDS resident (phx_adj2.hip)
     if (adj2_chunk(p->N, p->H, B, T, o->control) > 0)
         return adj2_run(p, t_all, B, T, o, y_saved_all, grad_y_all, adj_y0_all, grads, status_all, nfe_all, nsteps_all,

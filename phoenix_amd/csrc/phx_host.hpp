@@ -170,3 +170,20 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
              float *sol_all, int *status_all, int *nfe_all, int *nsteps_all, void *workspace, size_t workspace_bytes,
              hipStream_t st);
 }  // namespace phxh
+
+// ---- third-generation kernels for wide hidden layers (phx_fwd3c.hip / phx_adj3c.hip: dopri5, 48 < H <= 256, hidden chunks
+// of <= 48 rows)
+namespace phxh {
+int fwd3c_chunk(int N, int H, int B, int T, int control, int method);
+size_t fwd3c_workspace_bytes(int N, int H, int B, int T);
+int fwd3c_profile_region(int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups, int *plan6);
+int fwd3c_run(const phx_params *p, const float *y0_all, const double *t_all, int B, int T, const phx_solve_opts *o,
+              float *sol_all, int *status_all, int *nfe_all, int *nsteps_all, void *workspace, size_t workspace_bytes,
+              hipStream_t st);
+int adj3c_chunk(int N, int H, int B, int T, int control, int method);
+size_t adj3c_workspace_bytes(int N, int H, int B, int T);
+int adj3c_profile_region(int N, int H, int B, int T, int control, size_t *offset, int *n_workgroups, int *plan6);
+int adj3c_run(const phx_params *p, const double *t_all, int B, int T, const phx_solve_opts *o, const float *y_saved_all,
+              const float *grad_y_all, float *adj_y0_all, const phx_grads *grads, int *status_all, int *nfe_all,
+              int *nsteps_all, void *workspace, size_t workspace_bytes, hipStream_t st);
+}  // namespace phxh

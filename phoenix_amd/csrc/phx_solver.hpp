@@ -42,6 +42,8 @@ struct D1 {
     int Bcall; // > 0: the batch is `TG` independent odeint calls of Bcall trajectories (shared control per call), batch
                // group g = call g, rows [g*Bcall, (g+1)*Bcall) of the caller's arrays;  0: groups are Bt consecutive rows
     long long cntN;   // elements under one shared-control norm (rows of one call x N)
+    int res;   // chunked third-generation kernels (k1_solve_fwd3c / adj3c): 1 = the images of ALL hidden chunks of the
+               // workgroup's gene blocks stay LDS resident, 0 = one chunk slot, re-staged as the sweeps walk the chunks
 };
 
 struct W1 {

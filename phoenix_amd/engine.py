@@ -27,7 +27,8 @@ def _stream_ptr():
 
 _ws_bytes = {}
 _PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS", "PHX_FWD", "PHX_V3_NB",
-             "PHX_V3_HALF", "PHX_BATCH_MIN_ROWS", "PHX_PGRAD_WGS", "PHX_PGRAD_G4", "PHX_BATCH_CHUNK_MIN")
+             "PHX_V3_HALF", "PHX_BATCH_MIN_ROWS", "PHX_PGRAD_WGS", "PHX_PGRAD_G4", "PHX_BATCH_CHUNK_MIN", "PHX_V3C", "PHX_V3C_NB",
+             "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS")
 
 
 # phx_solve_opts.ws_keep: what the previous solve on a cached workspace was (plan key), so that the next identical one can
@@ -166,6 +167,10 @@ def _check_call(rc):
 
 
 def _raise(status, worst):
+    # A launch that ended in an error (above all PHX_ERR_SYNC_TIMEOUT, whose 5 s bail-out leaves the workspace header --
+    # exchange-set parity, `started` counters -- in an undefined state) must not be vouched for: the next solve on every
+    # cached workspace fills its exchange buffers again (phx_solve_opts.ws_keep = 0).
+    forget_workspaces()
     bad = int((status != 0).nonzero()[0].item())
     msg = "%s (trajectory %d)" % (_lib.STATUS_TEXT.get(worst, "status %d" % worst), bad)
     if worst in (1, 2, 3, 4):

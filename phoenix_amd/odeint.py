@@ -136,7 +136,13 @@ class _OdeintAdjointFn(torch.autograd.Function):
         if grad_sol is None:
             grad_sol = torch.zeros_like(sol)
         (method, control, rtol, atol, per_sample, t_is_f32, max_steps, adj, _defer) = ctx.cfg
-        a_method, a_rtol, a_atol = adj
+        a_method, a_rtol, a_atol, via_odeint = adj
+        if via_odeint and a_method != "dopri5":
+            raise NotImplementedError(
+                "phoenix_amd: backward through odeint(method='%s') on an ODENet would need backpropagation through the "
+                "fixed-grid steps, which the fused stepper does not record (the continuous adjoint differs from it at "
+                "O(1) for one unconverged step per interval); use odeint_adjoint -- the reference's training path, "
+                "adjoint.py:165" % a_method)
         p = ctx.phx_params
         if ctx.phx_versions != tuple(x._version for x in (ws, bs, wp, bp, wa, g)):
             p = engine.params_cached(ws, bs, wp, bp, wa, g)   # parameters were modified in place since forward
@@ -164,13 +170,23 @@ class _OdeintAdjointFn(torch.autograd.Function):
 
 
 def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, return_stats=False):
-    """Forward solve only (odeint.py:30-74).  The result carries no autograd history: the reference's
-    training/validation code always differentiates through `odeint_adjoint` (train_insilico.py:15-18)."""
+    """odeint.py:30-74.  The reference's `odeint` returns an autograd-tracked solution (backpropagation through the
+    solver's own operations).  The fused stepper keeps no such history, so for an ODENet:
+      * nothing requires grad, autograd is off (validation, analysis callers), or `return_stats`: plain forward solve;
+      * something requires grad: the call is routed through `odeint_adjoint`, so the result IS differentiable.  With
+        dopri5 the continuous adjoint agrees with backpropagation through the converged solve to the solver tolerance
+        (<= 2e-6 relative).  With a fixed grid (euler / midpoint / rk4: ONE step per interval,
+        far from converged) the two differ at O(1), and returning the adjoint's gradient silently would not be the
+        reference's `odeint`: the BACKWARD pass of such a call raises NotImplementedError (the forward result is
+        exact either way; PHOENIX itself trains through `odeint_adjoint`, train_insilico.py:15-18, which is
+        reproduced operation for operation)."""
     y0, t, rtol, atol, method, options = _check_inputs(func, y0, t, rtol, atol, method, options)
     if not _is_odenet(func):      # any other module: unfused torch stepper, differentiable by plain backpropagation
         engine._require_gpu(y0, "y0")          # like every other entry point: no CPU compute path in this package
         assert t.ndimension() == 1 and not return_stats, "per-sample grids / solver statistics need a PHOENIX ODENet"
         return generic.odeint(func, y0, t, rtol, atol, method, options)
+    if not return_stats and torch.is_grad_enabled() and (y0.requires_grad or any(x.requires_grad for x in params_of(func))):
+        return odeint_adjoint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options, _via_odeint=True)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
     engine.check_pending_status()
     p = engine.params_cached(*params)
@@ -207,7 +223,7 @@ def odeint_calls(func, y0s, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None, adjoint_rtol=None,
-                   adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None):
+                   adjoint_atol=None, adjoint_method=None, adjoint_options=None, adjoint_params=None, _via_odeint=False):
     """adjoint.py:165-204.  Gradients flow to y0 and to the six ODENet parameters."""
     if not _is_odenet(func):      # any other module: the reference's augmented system on the unfused torch stepper
         if adjoint_options:
@@ -236,9 +252,10 @@ def odeint_adjoint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None,
     # The forward status is read together with the backward solve's only when a backward pass can come: autograd must
     # be recording AND something must require grad (needs_input_grad mirrors .requires_grad even under no_grad: the
     # reference's validation code calls odeint_adjoint inside torch.no_grad(), train_insilico.py:77-106).
-    defer = torch.is_grad_enabled() and (y0.requires_grad or any(x.requires_grad for x in params))
+    # (a plain `odeint` call routed here keeps the reference's synchronous asserts: its caller may never run backward)
+    defer = torch.is_grad_enabled() and (y0.requires_grad or any(x.requires_grad for x in params)) and not _via_odeint
     cfg = (method, control, rtol, atol, per_sample, t_is_f32, int(options.get("max_num_steps", 0)),
-           (adjoint_method, float(adjoint_rtol), float(adjoint_atol)), defer)
+           (adjoint_method, float(adjoint_rtol), float(adjoint_atol), bool(_via_odeint)), defer)
     sol, _nfe = _OdeintAdjointFn.apply(y2, t64, cfg, *params)
     return _out_shape(sol, y0, per_sample)
 

@@ -48,6 +48,36 @@ def allreduce_grads(module, scale=None, extra=()):
         torch._foreach_mul_(grads, scale)
 
 
+def global_mean_weights(b_local, k_local, device=None):
+    """(B_local / B_global, K_local / K_global): the factors that turn a rank's local `torch.mean` losses into its share of
+    the reference's means over the WHOLE batch (train_insilico.py:132,136) when the ranks' shards are not equal (23 yeast
+    pairs over 8 ranks).  One small SUM all-reduce of the two counts; every rank must call it in the same step."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0, 1.0
+    cnt = torch.tensor([float(b_local), float(k_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    bg, kg = cnt.tolist()
+    return (b_local / bg if bg > 0 else 0.0), (k_local / kg if kg > 0 else 0.0)
+
+
+def _reduce_list(tensors, async_op=False):
+    """SUM all-reduce of a list of tensors in one grouped call where torch offers it (same decision on every rank)"""
+    if _has_coalesced():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return dist.all_reduce_coalesced(tensors, op=dist.ReduceOp.SUM, async_op=async_op)
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op) for g in tensors]
+    if not async_op:
+        return None
+
+    class _All:
+        def wait(self):
+            for w in works:
+                w.wait()
+    return _All()
+
+
 def zero_grads_where_failed(module, flag):
     """device-side guard of the deferred mode: where the summed failure flag is non-zero every gradient becomes 0 (no
     host round trip).  A select, not a multiply: the engine writes NaN into outputs a failed solve never reached, so the
@@ -77,9 +107,32 @@ class GradSync:
     restored from the last checkpoint on ALL ranks before training continues."""
     collective_errors = True
 
-    def __init__(self, scale=None):
+    def __init__(self, scale=None, global_batch=None, global_prior=None, weighted=False, overlap=False):
+        """`scale`: factor applied to the summed gradients (1 / world for EQUAL shards of a mean loss).
+        Unequal shards -- the reference's mean is over the global batch (train_insilico.py:132) -- need per-rank weights
+        instead: `global_batch` / `global_prior` (the global numbers of trajectories and prior rows, when the caller knows
+        them) or `weighted=True` (the counts are summed over the ranks every step, one small collective): training_step
+        then scales each rank's two losses by B_local / B_global and K_local / K_global and the gradients are SUMMED
+        (`scale` must stay None).
+        `overlap=True`: training_step differentiates the two losses separately and the all-reduce of the data-loss
+        gradients runs (async, on the process group's stream) while the prior branch's backward still computes; the two
+        reduced gradient sets are added afterwards."""
         self.scale = scale
+        self.global_batch, self.global_prior, self.weighted = global_batch, global_prior, weighted
+        self.overlap = overlap
+        if (weighted or global_batch is not None) and scale is not None:
+            raise ValueError("GradSync: per-rank loss weights already make the sum of the gradients the global gradient; "
+                             "scale must be None")
         self._pending = None     # (pinned host flag, event) of the previous call
+
+    def loss_weights(self, b_local, k_local, device=None):
+        """factors of this rank's (data, prior) mean losses; (1, 1) for equal shards (`scale` does the averaging)"""
+        if self.global_batch is not None:
+            kg = self.global_prior if self.global_prior is not None else k_local
+            return b_local / float(self.global_batch), (k_local / float(kg) if kg else 0.0)
+        if self.weighted:
+            return global_mean_weights(b_local, k_local, device)
+        return 1.0, 1.0
 
     def check(self):
         if self._pending is not None:
@@ -91,12 +144,25 @@ class GradSync:
 
     finish = check
 
-    def __call__(self, module, error=None):
+    def reduce_async(self, grads):
+        """starts the SUM all-reduce of a list of gradient tensors (stream ordered behind the kernels that wrote them) and
+        returns a handle whose wait() orders the current stream behind it; None without a process group"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        return _reduce_list([g for g in grads if g is not None], async_op=True)
+
+    def __call__(self, module, error=None, reduced=False):
+        """`reduced=True`: the gradients in `.grad` are already summed over the ranks (the overlapped path of
+        training_step): only the failure flag travels"""
         from . import engine
         self.check()
         dev = next(module.parameters()).device
         flag = torch.full((1,), 0.0 if error is None else 1.0, device=dev)
-        allreduce_grads(module, self.scale, extra=[flag])
+        if reduced:
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        else:
+            allreduce_grads(module, self.scale, extra=[flag])
         if error is not None:
             raise error
         if not (dist.is_available() and dist.is_initialized()):

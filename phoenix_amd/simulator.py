@@ -84,6 +84,113 @@ class _Compiler(ast.NodeVisitor):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The equation builder (GraphGRN_core.R:163-190, 221-236, 312-330): how the reference turns a node's logic equation and the
+# properties of its incoming edges into the rate-expression TEXT that it ships in ode_system_functions_*.csv.
+#   NODE(tf)  ->  "<weight> * fAct(<tf>, <EC50>, <n>)"            (NODE: R:163-169, generateActivationEqnReg: R:312-330)
+#   NOT(e)    ->  "(1 - e)"                                       (R:171-174)
+#   AND(a, b) ->  "(a * b)"                                       (R:176-179)
+#   OR(a, b)  ->  "(a + b - a * b)"                               (R:182-185)
+#   rate      ->  "((act) * spmax - spdeg * NAME) / tau"          (generateRateEqn_modified: R:221-236)
+# A logic tree is ("node", tf) | ("not", t) | ("and", a, b) | ("or", a, b).  The logic equations themselves are drawn at
+# random when the reference builds its graph (genericLogicEqn, R:727-800: `runif(...) < propor`) and are NOT shipped, so
+# they are recovered from the shipped expression text (`logic_of_expression`); what the pin (golden G16,
+# tests/test_simulator_cpu.py) then checks is that `rate_expression(logic, edge properties)` reproduces every shipped
+# expression text for text from edge_properties_G*.csv -- weights, EC50 and Hill constants as R printed them -- and that an
+# edge is negated exactly where its `activation` flag is FALSE.
+# ---------------------------------------------------------------------------------------------------------------------
+def activation_text(edge):
+    """`weight * fAct(from, EC50, n)` of one edge; `edge`: dict with the CSV's text fields from, weight, EC50, n"""
+    return "%s * fAct(%s, %s, %s)" % (edge["weight"], edge["from"], edge["EC50"], edge["n"])
+
+
+def logic_text(tree, node, edges):
+    kind = tree[0]
+    if kind == "node":
+        return activation_text(edges[(tree[1], node)])
+    if kind == "not":
+        return "(1 - %s)" % logic_text(tree[1], node, edges)
+    a, b = logic_text(tree[1], node, edges), logic_text(tree[2], node, edges)
+    if kind == "and":
+        return "(%s * %s)" % (a, b)
+    if kind == "or":
+        return "(%s + %s - %s * %s)" % (a, b, a, b)
+    raise ValueError("unknown logic operator %r" % (kind,))
+
+
+def rate_expression(node, tree, edges, spmax="1", spdeg="1", tau="1"):
+    """generateRateEqn_modified (R:221-236) for a non-input node"""
+    return "((%s) * %s - %s * %s) / %s" % (logic_text(tree, node, edges), spmax, spdeg, node, tau)
+
+
+def logic_of_expression(expr, node):
+    """inverse of `rate_expression`: (logic tree, spmax, spdeg, tau) recovered from a shipped expression string"""
+    import re
+    m = re.fullmatch(r"\(\((.*)\) \* (\S+) - (\S+) \* %s\) / (\S+)" % re.escape(node), expr)
+    if not m:
+        raise ValueError("not a rate expression of node %s: %s" % (node, expr[:80]))
+    body, spmax, spdeg, tau = m.groups()
+    pos = [0]
+
+    def peek(txt):
+        return body.startswith(txt, pos[0])
+
+    def eat(txt):
+        if not peek(txt):
+            raise ValueError("expected %r at %d in %s" % (txt, pos[0], body[:120]))
+        pos[0] += len(txt)
+
+    def term():
+        if peek("(1 - "):
+            eat("(1 - ")
+            t = term()
+            eat(")")
+            return ("not", t)
+        if peek("("):
+            eat("(")
+            a = term()
+            if peek(" * "):
+                eat(" * ")
+                b = term()
+                eat(")")
+                return ("and", a, b)
+            eat(" + ")
+            b = term()
+            eat(" - ")
+            a2 = term()
+            eat(" * ")
+            b2 = term()
+            eat(")")
+            if a2 != a or b2 != b:
+                raise ValueError("malformed OR in %s" % body[:120])
+            return ("or", a, b)
+        m2 = re.compile(r"([0-9.eE+-]+) \* fAct\((\w+), ([0-9.eE+-]+), ([0-9.eE+-]+)\)").match(body, pos[0])
+        if not m2:
+            raise ValueError("expected an activation term at %d in %s" % (pos[0], body[:120]))
+        pos[0] = m2.end()
+        return ("node", m2.group(2), m2.group(1), m2.group(3), m2.group(4))
+
+    t = term()
+    if pos[0] != len(body):
+        raise ValueError("trailing text in %s" % body[:120])
+
+    def strip(x):   # leaves keep only the regulator's name: weight / EC50 / n come from the edge table when rebuilding
+        return ("node", x[1]) if x[0] == "node" else (x[0],) + tuple(strip(y) for y in x[1:])
+
+    def leaves(x, neg=False, out=None):
+        out = [] if out is None else out
+        if x[0] == "node":
+            out.append((x[1], x[2], x[3], x[4], neg))
+        elif x[0] == "not":
+            leaves(x[1], not neg, out)
+        else:
+            for y in x[1:]:
+                leaves(y, neg, out)
+        return out
+
+    return strip(t), spmax, spdeg, tau, leaves(t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # External inputs of a simulated data set (SimulationGRN_core_init_var.R:40-160).  Host-side sampling, as in the reference
 # (R); the draws come from numpy's generator, so a data set is statistically, not bitwise, the reference's.
 # ---------------------------------------------------------------------------------------------------------------------

@@ -558,6 +558,22 @@ def g11_hill():
     save("g11_hill", names=np.array(names), eqns=np.array(exprs), X=X, rates=rates, times=times, x0=x0, traj=traj)
 
 
+def g16_edges():
+    """The shipped edge tables of the two in-silico networks (reference DATA: ground_truth_simulator/clean_data/
+    edge_properties_G350.csv / _G690.csv -- from, to, weight, activation, EC50, n exactly as R printed them) as text arrays:
+    the inputs from which GraphGRN_core.R:163-190,221-236 builds the rate-expression strings of G11 / G13.  Pins the
+    equation builder of phoenix_amd/simulator.py (rate_expression) text for text at 350 genes; the shipped 690-gene table
+    comes from another draw of the random EC50 / n than the shipped 690-gene expressions (every value differs), so there
+    only the structure (every regulator is an edge, negated exactly where activation is FALSE) can be held."""
+    import csv
+    out = {}
+    for tag in ("350", "690"):
+        rows = list(csv.DictReader(open("/root/reference/ground_truth_simulator/clean_data/edge_properties_G%s.csv" % tag)))
+        for k in ("from", "to", "weight", "activation", "EC50", "n"):
+            out["e%s_%s" % (tag, k)] = np.array([r[k] for r in rows])
+    save("g16_edges", **out)
+
+
 def g13_hill690():
     """G11 for the second shipped network: ground_truth_simulator/clean_data/ode_system_functions_690.csv (690 nodes).
     Same recipe -- expression strings as input arrays, Python fp64 rates on random states, scipy LSODA trajectories."""
@@ -669,7 +685,7 @@ def g14_g15_fullsize(which=("g14", "g15")):
 if __name__ == "__main__":
     for only, fn in (("--only-g8", "g8_prior"), ("--only-g9", "g9_datahandler"), ("--only-g10", "g10_analysis"),
                      ("--only-g11", "g11_hill"), ("--only-g12", "g12_spread"),
-                     ("--only-g13", "g13_hill690"), ("--only-g14", "g14_g15_fullsize")):
+                     ("--only-g13", "g13_hill690"), ("--only-g14", "g14_g15_fullsize"), ("--only-g16", "g16_edges")):
         if only in sys.argv:
             globals()[fn]()
             sys.exit(0)
@@ -686,3 +702,4 @@ if __name__ == "__main__":
     g13_hill690()
     g12_spread()
     g14_g15_fullsize()
+    g16_edges()

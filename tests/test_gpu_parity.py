@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, net_from, relerr, sub
+from conftest import GRAD_ERRORS, grad_err, load_golden, net_from, relerr, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -136,10 +136,10 @@ def test_g4_dopri5(pa, dev, tname, yname):
         y0r = y0.clone().requires_grad_(True)
         s2 = pa.odeint_adjoint(net, y0r, t)
         (s2 * torch.from_numpy(c["G"]).to(dev)).sum().backward()
-        assert relerr(y0r.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+        assert grad_err(y0r.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
         got = grads_of(net)
         for k in KEYS:
-            assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+            assert grad_err(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
 
 
 def test_g12_gradients_are_as_close_to_the_truth_as_the_references_own(pa, dev):
@@ -178,10 +178,10 @@ def test_g4_per_sample_loop_as_one_launch(pa, dev):
     pred = pa.odeint_adjoint(net, y0, t)[1]
     assert relerr(pred.detach().cpu().numpy(), c["pred"]) < TOL_DOPRI
     (pred * torch.from_numpy(c["G"]).to(dev)).sum().backward()
-    assert relerr(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+    assert grad_err(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
     got = grads_of(net)
     for k in KEYS:
-        assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
 
 
 class _Handler:
@@ -276,10 +276,10 @@ def test_g7_realdata(pa, dev, name):
         sol = pa.odeint_adjoint(net, y0, t)
         assert relerr(sol.detach().cpu().numpy(), c["sol"]) < TOL_DOPRI
         (sol * torch.from_numpy(c["G"]).to(dev)).sum().backward()
-        assert relerr(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
+        assert grad_err(y0.grad.cpu().numpy(), c["grad_y0"]) < TOL_DOPRI_GRAD
         got = grads_of(net)
         for k in KEYS:
-            assert relerr(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
+            assert grad_err(got[k], c["grad_" + k]) < TOL_DOPRI_GRAD, k
 
 
 @pytest.mark.parametrize("name,gtol", [("g14_breast11165", TOL_DOPRI_GRAD_1STEP), ("g15_yeast3551", TOL_DOPRI_GRAD)])
@@ -495,7 +495,7 @@ def test_full_size_breast_properties(pa, dev, oracle):
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
     adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
                                                           method="dopri5", theta_in_norm=True)
-    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     full = grads_of(net)
     # parameter gradients at full size against the oracle: the engine on exactly the sampled rows (the quadrature
     # kernel at N = 11165; linearity over sub-batches below ties the 256-row gradient to such pieces)
@@ -505,7 +505,7 @@ def test_full_size_breast_properties(pa, dev, oracle):
     (sr * G[:, rows]).sum().backward()
     g_rows = grads_of(net)
     for k in KEYS:
-        assert relerr(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
     # batch invariance: a sub-batch gives the same rows
     sub_rows = list(range(16, 48))
     s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
@@ -554,6 +554,40 @@ def test_full_size_breast_every_row_vs_oracle(pa, dev, oracle, B):
         assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD_1STEP, k
 
 
+def test_bench_inputs_breast_vs_oracle(pa, dev, oracle):
+    """The EXACT inputs `bench.py` times at its default workload (C4: `bench.make_problem(WORKLOADS["breast"], seed 0)` --
+    trained-like dense N(0, 0.05^2) factors, not the std 0.02 of the other full-size tests -- and the bench's own
+    cotangent): 16 rows of the trajectories and of dL/dy0, and all six parameter gradients of the whole 256-row batch,
+    against the oracle running the reference's per-sample loop with the parameter block in the adjoint norm."""
+    import bench
+    wl = bench.WORKLOADS["breast"]
+    N, H, B = wl["N"], wl["H"], wl["B"]
+    net, y0, t = bench.make_problem(wl, dev, seed=0)
+    T = t.shape[1]
+    gg = torch.Generator(device="cpu").manual_seed(100)              # bench.py: problem(): rank 0's cotangent
+    G = (torch.randn(T, B, 1, N, generator=gg) / (B * N)).to(dev)
+    G[0].zero_()
+    p = {"Ws": net.net_sums.linear_out.weight, "bs": net.net_sums.linear_out.bias, "Wp": net.net_prods.linear_out.weight,
+         "bp": net.net_prods.linear_out.bias, "Wa": net.net_alpha_combine.linear_out.weight, "g": net.gene_multipliers}
+    p = {k: v.detach().cpu().numpy().reshape(-1) if k == "g" else v.detach().cpu().numpy() for k, v in p.items()}
+    onet = onet_of(oracle, p)
+    zero_grads(net)
+    y = y0.detach().requires_grad_(True)
+    sol = pa.odeint_adjoint(net, y, t, method=wl["method"])
+    torch.autograd.backward(sol, G)                                   # the bench's step
+    y0n, tn = y0.cpu().numpy().reshape(B, N), t.cpu().numpy()
+    Gn = G.cpu().numpy().reshape(T, B, N).transpose(1, 0, 2).copy()
+    ref = oracle.odeint_per_sample(onet, y0n, tn, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, tn, ref, Gn, method="dopri5", theta_in_norm=True)
+    rows = list(range(0, B, 16))
+    got = sol.detach().cpu().numpy().reshape(T, B, N).transpose(1, 0, 2)
+    assert relerr(got[rows], ref[rows]) < TOL_DOPRI
+    assert relerr(y.grad.cpu().numpy().reshape(B, N)[rows], adj_ref[rows]) < TOL_DOPRI_GRAD_1STEP
+    gnet = grads_of(net)
+    for k in KEYS:
+        assert relerr(gnet[k], gr_ref[k]) < TOL_DOPRI_GRAD_1STEP, k
+
+
 def test_full_size_bcell_rows_of_every_group_vs_oracle(pa, dev, oracle):
     """BASELINE config C5 at full size (N=14691, H=200 -> two hidden chunks, B=256, dopri5 + adjoint over [0, 1]): 32 rows
     that cover every batch group and the first and last trajectory tile of each, against the oracle with the parameter
@@ -578,15 +612,15 @@ def test_full_size_bcell_rows_of_every_group_vs_oracle(pa, dev, oracle):
     (sol * Gt).sum().backward()
     got = sol.detach()[:, rows, 0].cpu().numpy().transpose(1, 0, 2)
     assert relerr(got, ref) < TOL_DOPRI
-    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     zero_grads(net)
     yr = y0t.detach()[rows].clone().requires_grad_(True)
     sr = pa.odeint_adjoint(net, yr, tt[rows])
     (sr * Gt[:, rows]).sum().backward()
-    assert relerr(yr.grad[:, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(yr.grad[:, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     gg = grads_of(net)
     for k in KEYS:
-        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
 
 
 def test_full_size_insilico_vs_oracle(pa, dev, oracle):
@@ -632,10 +666,10 @@ def test_full_size_yeast_vs_oracle(pa, dev, oracle):
     got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
     assert relerr(got, ref) < TOL_DOPRI
     (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
-    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD
     gg = grads_of(net)
     for k in KEYS:
-        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
 
 
 def test_full_size_bcell_properties(pa, dev, oracle):
@@ -662,7 +696,7 @@ def test_full_size_bcell_properties(pa, dev, oracle):
     assert relerr(s[:, rows, 0].cpu().numpy().transpose(1, 0, 2), ref) < TOL_DOPRI
     adj_ref, gr_rows = oracle.adjoint_backward_per_sample(onet, t[rows], ref, G[:, rows, 0].cpu().numpy().transpose(1, 0, 2),
                                                           method="dopri5", theta_in_norm=True)
-    assert relerr(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad[rows, 0].cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     full = grads_of(net)
     zero_grads(net)                                  # parameter gradients of exactly the sampled rows against the oracle
     yr = y0t.detach()[rows].clone().requires_grad_(True)
@@ -670,7 +704,7 @@ def test_full_size_bcell_properties(pa, dev, oracle):
     (sr * G[:, rows]).sum().backward()
     g_rows = grads_of(net)
     for k in KEYS:
-        assert relerr(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(g_rows[k], gr_rows[k]) < TOL_DOPRI_GRAD, k
     sub_rows = list(range(100, 132))
     s2 = pa.odeint(net, y0t.detach()[sub_rows], tt[sub_rows])
     assert relerr(s2[1].cpu().numpy(), s[1, sub_rows].cpu().numpy()) < 2e-6
@@ -976,10 +1010,10 @@ def test_shared_control_adjoint_multi_interval_vs_oracle(pa, dev, oracle, monkey
     sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
     assert relerr(sol.detach().cpu().numpy(), ref) < TOL_DOPRI
     (sol * torch.from_numpy(G).to(dev)).sum().backward()
-    assert relerr(y0t.grad.cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad.cpu().numpy(), adj_ref) < TOL_DOPRI_GRAD
     gg = grads_of(net)
     for k in KEYS:
-        assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
 
 
 @pytest.mark.parametrize("N,H,B,method", [(700, 250, 5, "dopri5"), (300, 131, 20, "rk4"), (300, 131, 4, "dopri5")])
@@ -1040,10 +1074,10 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
         got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
         assert relerr(got, ref) < TOL_DOPRI, (N, H)
         (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
-        assert relerr(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD, (N, H)
+        assert grad_err(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD, (N, H)
         gg = grads_of(net)
         for k in KEYS:
-            assert relerr(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
+            assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
 @pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 1100), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100)])
@@ -1482,7 +1516,19 @@ def test_other_stream_and_mixed_time_directions(pa, dev, oracle):
     assert relerr(got_sol, ref) < TOL_DOPRI
     adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G.reshape(3, B, N).transpose(1, 0, 2).copy(),
                                                          method="dopri5")[:2]
-    assert relerr(y0t.grad.cpu().numpy().reshape(B, N), np.asarray(adj_ref).reshape(B, N)) < TOL_DOPRI_GRAD
+    assert grad_err(y0t.grad.cpu().numpy().reshape(B, N), np.asarray(adj_ref).reshape(B, N)) < TOL_DOPRI_GRAD
     got = grads_of(net)
     for k in KEYS:
-        assert relerr(got[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+        assert grad_err(got[k], gr_ref[k]) < TOL_DOPRI_GRAD, k
+
+
+
+def test_zz_median_gradient_error_of_the_suite_meets_the_north_star_bar():
+    """Runs last (file order): the MEDIAN engine-vs-reference error of every multi-step dopri5 gradient comparison this
+    session made (oracle with the parameter block in the norm, goldens captured from torchdiffeq) is within the
+    north-star 1e-5; single cases may sit at the accept/reject noise ceiling TOL_DOPRI_GRAD (golden G12: the reference's
+    own gradients scatter 7.7e-6 median / 1.3e-5 max around the fp64 truth at rtol = 1e-7)."""
+    if len(GRAD_ERRORS) < 20:
+        pytest.skip("only %d gradient comparisons were made in this session (a partial run)" % len(GRAD_ERRORS))
+    v = np.array([e for e, _ in GRAD_ERRORS])
+    assert float(np.median(v)) <= 1e-5, (float(np.median(v)), float(v.max()))

@@ -253,3 +253,89 @@ def test_shard_range_covers_everything():
             assert pieces[0][0] == 0 and pieces[-1][1] == n
             for a, b in zip(pieces, pieces[1:]):
                 assert a[1] == b[0]
+
+
+def _problem_unequal():
+    g = torch.Generator().manual_seed(5)
+    B, n, K = 23, 5, 11                 # 23 yeast pairs (config_yeast.cfg) over 2 ranks: 12 + 11 trajectories, 6 + 5 prior rows
+    batch = torch.rand(B, 1, n, generator=g)
+    t = torch.stack([torch.zeros(B), 0.1 + 0.05 * torch.arange(B)], 1)
+    target = torch.rand(B, 1, n, generator=g)
+    X = torch.rand(K, 1, n, generator=g)
+    prior = torch.rand(K, 1, n, generator=g)
+    return B, n, K, batch, t, target, X, prior
+
+
+def _unequal_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from phoenix_amd import parallel, training
+    training.odeint_adjoint = _stub_odeint_adjoint
+    B, n, K, batch, t, target, X, prior = _problem_unequal()
+    torch.manual_seed(1)
+    net = _StubNet(n)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    lo, hi = parallel.shard_range(B, rank, world)
+    klo, khi = parallel.shard_range(K, rank, world)
+    h = _Handler(batch[lo:hi], t[lo:hi], target[lo:hi])
+    if mode == "counts":
+        sync = parallel.GradSync(weighted=True)                              # counts summed over the ranks every step
+    elif mode == "known":
+        sync = parallel.GradSync(global_batch=B, global_prior=K)             # the caller knows the global sizes
+    else:
+        sync = parallel.GradSync(weighted=True, overlap=True)                # + data-loss all-reduce under the prior backward
+    losses = training.training_step(net, h, opt, "dopri5", hi - lo, False, False, X[klo:khi], prior[klo:khi], 0.7,
+                                    grad_sync=sync)
+    wd, wp = (hi - lo) / B, (khi - klo) / K
+    tot = parallel.allreduce_scalars(losses[0] * wd, losses[1] * wp)
+    q.put((rank, [p.detach().reshape(-1).tolist() for p in net.parameters()], [float(x) for x in tot], (hi - lo, khi - klo)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_shards_reproduce_the_global_mean_losses():
+    """B = 23 trajectories and K = 11 prior rows over 2 ranks (12 + 11, 6 + 5): with GradSync's per-rank loss weights
+    (B_local / B_global, K_local / K_global) the two-rank step equals the single-process step with the whole batch
+    (the reference's torch.mean over everything, train_insilico.py:132,136) to 1e-6 -- in all three forms: counts
+    all-reduced per step, global sizes given, and with the data-loss all-reduce overlapped with the prior backward."""
+    import pytest
+    from phoenix_amd import training
+    B, n, K, batch, t, target, X, prior = _problem_unequal()
+    torch.manual_seed(1)
+    net = _StubNet(n)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    saved = training.odeint_adjoint
+    training.odeint_adjoint = _stub_odeint_adjoint
+    try:
+        losses = training.training_step(net, _Handler(batch, t, target), opt, "dopri5", B, False, False, X, prior, 0.7)
+    finally:
+        training.odeint_adjoint = saved
+    ref = [p.detach().reshape(-1) for p in net.parameters()]
+    world = 2
+    for k, mode in enumerate(("counts", "known", "overlap")):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 37500 + (os.getpid() % 1500) + 3 * k
+        procs = [ctx.Process(target=_unequal_worker, args=(r, world, port, q, mode)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(r[3] for r in res) == [(11, 5), (12, 6)]
+        for _, params, tot, _ in res:
+            for a, b in zip(params, ref):
+                assert torch.allclose(torch.tensor(a), b, rtol=1e-6, atol=1e-6), mode
+            assert tot[0] == pytest.approx(float(losses[0]), rel=1e-6) and tot[1] == pytest.approx(float(losses[1]), rel=1e-6)
+
+
+def test_gradsync_rejects_scale_with_weights():
+    import pytest
+    from phoenix_amd import parallel
+    with pytest.raises(ValueError):
+        parallel.GradSync(scale=0.5, weighted=True)
+    assert parallel.GradSync(global_batch=23, global_prior=11).loss_weights(12, 6) == (12 / 23.0, 6 / 11.0)
+    assert parallel.GradSync(scale=0.5).loss_weights(12, 6) == (1.0, 1.0)

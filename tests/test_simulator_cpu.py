@@ -185,3 +185,57 @@ def test_initial_states_use_the_input_models_for_input_genes():
     assert x.shape == (500, 4) and x.dtype == np.float32 and x.min() >= 0 and x.max() <= 1
     # input genes: one truncated normal each (tight), regulated genes: Beta(2,2) + shift (wide)
     assert x[:, 0].std() < 0.17 and x[:, 2].std() < 0.17 and x[:, 1].std() > 0.17 and x[:, 3].std() > 0.17
+
+
+def _edges(tag):
+    g = load_golden("g16_edges")
+    cols = {k: g["e%s_%s" % (tag, k)] for k in ("from", "to", "weight", "activation", "EC50", "n")}
+    return {(str(f), str(t)): {k: str(cols[k][i]) for k in cols}
+            for i, (f, t) in enumerate(zip(cols["from"], cols["to"]))}
+
+
+def test_equation_builder_reproduces_the_shipped_expressions_text_for_text():
+    """Row f4, the equation-builder half (GraphGRN_core.R:163-190 NODE / NOT / AND / OR, :221-236 generateRateEqn_modified,
+    :312-330 the activation term): `simulator.rate_expression(logic, edge table)` rebuilds EVERY non-input row of the shipped
+    ode_system_functions_350.csv (golden G11) character for character from the shipped edge_properties_G350.csv (golden
+    G16: weights, EC50 and Hill constants as R printed them), and an edge sits under a NOT exactly where its
+    `activation` flag is FALSE.  The logic equations themselves are random draws of the reference's graph construction
+    (genericLogicEqn, R:727-800) that are not shipped: they are recovered from the expression text."""
+    from phoenix_amd import simulator as sim
+    g = load_golden("g11_hill")
+    edges = _edges("350")
+    n, used = 0, set()
+    for node, eqn in zip(g["names"], g["eqns"]):
+        node, eqn = str(node), str(eqn)
+        if eqn == "input gene":
+            continue
+        tree, spmax, spdeg, tau, leaves = sim.logic_of_expression(eqn, node)
+        assert sim.rate_expression(node, tree, edges, spmax, spdeg, tau) == eqn, node
+        for tf, w, ec50, hill, neg in leaves:
+            e = edges[(tf, node)]
+            used.add((tf, node))
+            assert (e["weight"], e["EC50"], e["n"]) == (w, ec50, hill) and (e["activation"] == "FALSE") == neg, (tf, node)
+        n += 1
+    assert n == 276 and len(used) >= 547          # every rate expression; all but three of the 550 shipped edges occur
+
+
+def test_equation_structure_of_the_690_gene_network_matches_its_edge_table():
+    """The shipped edge_properties_G690.csv is NOT the table the shipped 690-gene expressions were printed from (every
+    EC50 / n differs: another draw), so only the structure can be held there: every regulator in an expression is an edge
+    of the table, negated exactly where `activation` is FALSE, and the builder reproduces each expression from its own
+    constants."""
+    from phoenix_amd import simulator as sim
+    g = load_golden("g13_hill690")
+    edges = _edges("690")
+    n = 0
+    for node, eqn in zip(g["names"], g["eqns"]):
+        node, eqn = str(node), str(eqn)
+        if eqn == "input gene":
+            continue
+        tree, spmax, spdeg, tau, leaves = sim.logic_of_expression(eqn, node)
+        own = {(tf, node): {"from": tf, "weight": w, "EC50": ec50, "n": hill} for tf, w, ec50, hill, _ in leaves}
+        assert sim.rate_expression(node, tree, own, spmax, spdeg, tau) == eqn, node
+        for tf, _w, _e, _h, neg in leaves:
+            assert (edges[(tf, node)]["activation"] == "FALSE") == neg, (tf, node)
+        n += 1
+    assert n == 593
