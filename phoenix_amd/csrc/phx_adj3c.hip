@@ -218,10 +218,11 @@ int adj3c_run(const phx_params *p, const double *t_all, int B, int T, const phx_
         if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
         // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
         if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
-        ev_begin(st);
+        // (diagnostic kernel events: ONE pair around all launches of a batch that runs in several)
+        if (b0 == 0) ev_begin(st);
         const hipError_t lerr = launch_persistent(fn, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, t, y_saved, grad_y, adj_y0,
                                                   status, nfe, nsteps, (int)(grads ? 1 : 0), PP);
-        ev_end(st);
+        if (b0 + chunk >= B) ev_end(st);
         if (lerr != hipSuccess || hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
         if (grads) {
             const long long total = (long long)d1.nblk * d1.HC * (4 * d1.HT * 2 * 64) + p->N + 2 * p->H;

@@ -195,9 +195,9 @@ int fwd3c_run(const phx_params *p, const float *y0_all, const double *t_all, int
             if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
             // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
             if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;
-            ev_begin(st);
+            if (b0 == 0) ev_begin(st);   // (ONE event pair around all launches of a batch that runs in several)
             const hipError_t lerr = launch_persistent(fn, grid1, blk1, lds, st, to_net(p), d1, w1, cfg, y0, t, sol, status, nfe, nsteps);
-            ev_end(st);
+            if (b0 + chunk >= B) ev_end(st);
             return lerr == hipSuccess ? PHX_OK : PHX_ERR_LAUNCH;
         };
         const bool half = d1.Hc <= 40;   // every chunk's last tile has at most 8 live rows (rho16, phx_mfma_v3common.inc)

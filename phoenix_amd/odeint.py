@@ -206,7 +206,8 @@ def odeint_calls(func, y0s, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     exist (shapes served by the VALU engine)."""
     K = y0s.shape[0]
     if K == 1:
-        return odeint(func, y0s[0], t, rtol, atol, method, options).unsqueeze(0)
+        with torch.no_grad():     # forward-only by contract, like the batched launch below
+            return odeint(func, y0s[0], t, rtol, atol, method, options).unsqueeze(0)
     y0, t, rtol, atol, method, options = _check_inputs(func, y0s, t, rtol, atol, method, options)
     params, y2, t64, B, N, per_sample, t_is_f32, control = _prepare(func, y0, t, options)
     if per_sample or control != _lib.CTRL_SHARED:
@@ -217,7 +218,8 @@ def odeint_calls(func, y0s, t, rtol=1e-7, atol=1e-9, method=None, options=None):
         sol, status, _, _ = engine.solve_forward(p, y2.detach().contiguous(), t64, method, control, rtol, atol, per_sample,
                                                  t_is_f32, int(options.get("max_num_steps", 0)), calls=K)
     except ValueError:
-        return torch.stack([odeint(func, y0s[k], t, rtol, atol, method, options) for k in range(K)])
+        with torch.no_grad():
+            return torch.stack([odeint(func, y0s[k], t, rtol, atol, method, options) for k in range(K)])
     engine.raise_for_status(status)
     return sol.reshape((sol.shape[0], K) + tuple(y0s.shape[1:])).transpose(0, 1)
 

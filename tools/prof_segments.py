@@ -66,13 +66,23 @@ if kern == 3:
              "block: tile wait", "block: consume tiles + requests", "block: P2' + k", "block: input + act + P1'"]
     if os.environ["PHX_PROF"] == "3":
         names[10:16] = ["quad: other (loop, requests)", "quad: tile wait", "quad: seven stages", "quad: partial stores", "quad: accept pass", "quad: acquire"]
+fk = lib.phx_debug_forward_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, _lib.METHODS[wl["method"]])
+if which == "fwd" and fk == 4:      # chunked third generation (phx_mfma_fwd3c.inc)
+    names = ["other (barriers, tails)", "phase F: P1 only", "phase F: fused P2+P1", "reduce-scatter", "gather hidden rows (phase F, 1st tile)",
+             "phase F: P2 only", "init(weights,y0)", "chunk staging (+barriers)", "norms (reduce+gather)", "controller + ring",
+             "accept pass (dense output)", "phase A: P2 of chunks 0..HC-2 (+gathers)", "phase C: P1 of chunks HC-2..0", "-", "-", "-"]
+if kern == 4:                       # chunked third generation (phx_mfma_adj3c.inc)
+    names = ["other (barriers, tails)", "phase F: P1' only", "phase F: fused P2'+P1'", "reduce-scatter (+FSAL rows)",
+             "gather hidden rows (phase F, 1st tile)", "phase F: P2' only", "init(weights,y0)", "-", "norms (reduce+gather)",
+             "controller + ring", "quadrature", "phase A: P2' of chunks 0..HC-2 (+gathers)", "phase C: P1' of chunks HC-2..0",
+             "chunk staging (+barriers)", "accept pass", "-"]
 if second:
     names = ["other (between blocks)", "sweep tail P1-only", "drain+flag+publish", "reduce owned rows", "gather hidden rows", "sweep tail fused", "init(weights,y0)", "-", "norms (gather+pair sync)", "controller", "accept pass", "quadrature", "block: tile wait", "block: finish (VALU)", "block: requests+P1+P2 MFMA", "-"]
 clk = None
 if second:
     clk = raw[:, 15].astype(np.float64).copy()
     us[:, 15] = 0
-if kern == 3:
+if kern in (3, 4):
     clk = raw[:, 7].astype(np.float64).copy()
     us[:, 7] = 0
 tot = us.sum(1)

@@ -175,6 +175,8 @@ if __name__ == "__main__":
         case("mixed directions", 350, 120, 6, [[0.0, 0.3, 0.7] if b % 2 == 0 else [1.0, 0.6, 0.1] for b in range(6)], 0.5 / np.sqrt(350))
         # one re-staged slot, forced
         case("H=120 restaged NB=2", 777, 120, 70, grids(70, 0.0, 0.3, spread=0.003), 0.03, env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "2"})
+        case("H=64 (HC even) NB=2 slots", 350, 64, 40, grids(40, 0.0, 0.5, spread=0.01), 0.04, env={"PHX_V3C_NB": "2"})
+        case("H=200 restaged NB=4", 1500, 200, 50, grids(50, 0.0, 0.2, spread=0.002), 0.02, env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "4"})
         case("H=200 restaged TPW=2 NB=4", 1500, 200, 100, grids(100, 0.0, 0.2, spread=0.002), 0.02,
              env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "4", "PHX_V3C_TPW": "2"})
         case("H=200 restaged TPW=4 NB=2", 900, 200, 200, grids(200, 0.0, 0.2, spread=0.001), 0.02,
