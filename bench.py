@@ -507,6 +507,8 @@ def main(args):
         fwd_kernel = {0: "k_solve_fwd", 1: "k1_solve_fwd", 3: "k1_solve_fwd3", 4: "k1_solve_fwd3c"}[
             _lib.load().phx_debug_forward_kernel_m(N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid)]
         dom = adj_kernel if adj_ms_avg >= fwd_ms_avg else fwd_kernel   # key into the PMC summary
+        dom_launches = max(1, _lib.load().phx_debug_solve_launches(
+            _lib.OP_ADJOINT if dom == adj_kernel else _lib.OP_ODEINT, N, H, B, T, _lib.CTRL_PER_TRAJECTORY, mid))
         alg, flop, ms = (alg_adj, flop_adj, adj_ms_avg) if dom == adj_kernel else (alg_fwd, flop_fwd, fwd_ms_avg)
         achieved = alg / (ms * 1e-3) / 1e9
         # Which roof binds: arithmetic intensity of the algorithmic figures against the fp32 ridge of the part
@@ -533,7 +535,8 @@ def main(args):
                         pmc_note = ("%s was collected on another build of libphoenix_hip.so (sha256 %s, running %s): traffic "
                                     "not reported" % (os.path.basename(cand), str(pmc.get("library_sha256"))[:12], lib_sha[:12]))
                         break
-                    traffic = (2.0 * pmc["FETCH_SIZE_KB_per_launch"][dom] + pmc["WRITE_SIZE_KB_per_launch"][dom]) * 1024.0
+                    # (per-launch counters x the launches one solve of this batch makes: 256 B-cell trajectories = two)
+                    traffic = (2.0 * pmc["FETCH_SIZE_KB_per_launch"][dom] + pmc["WRITE_SIZE_KB_per_launch"][dom]) * 1024.0 * dom_launches
                     pmc_file = os.path.relpath(cand, ROOT)
                     break
                 except Exception as exc:   # noqa: BLE001
@@ -554,7 +557,7 @@ def main(args):
                                        "same library build, sha256 %s; not measured in this run)"
                                        % (pmc_file, lib_sha[:12])) if traffic else pmc_note,
                     "library_sha256": lib_sha,
-                    "algorithmic_bytes_per_launch": alg, "launch_ms": ms,
+                    "algorithmic_bytes_per_launch": alg, "launch_ms": ms, "launches_per_solve": dom_launches,
                     "forward": {"kernel": fwd_kernel, "launch_ms": fwd_ms_avg, "GBps": alg_fwd / (fwd_ms_avg * 1e-3) / 1e9,
                                 "TFLOPs": flop_fwd / (fwd_ms_avg * 1e-3) / 1e12, "batch_evals": nfe_fwd / B},
                     "adjoint": {"kernel": adj_kernel, "launch_ms": adj_ms_avg, "GBps": alg_adj / (adj_ms_avg * 1e-3) / 1e9,

@@ -218,8 +218,13 @@ int phx_debug_profile_region(int op, int N, int H, int B, int T, int control, si
 int phx_debug_adjoint_kernel(int N, int H, int B, int T, int control);
 int phx_debug_adjoint_kernel_m(int N, int H, int B, int T, int control, int method);
 /* ... and which forward-solve kernel phx_odeint launches: 0 = k_solve_fwd (VALU), 1 = k1_solve_fwd (MFMA),
- * 3 = k1_solve_fwd3 (MFMA, dopri5 with H <= 48). */
+ * 3 = k1_solve_fwd3 (MFMA, dopri5 with H <= 48), 4 = k1_solve_fwd3c (its hidden-chunked form, 48 < H <= 256); the
+ * adjoint query above likewise returns 4 for k1_solve_adj3c. */
 int phx_debug_forward_kernel_m(int N, int H, int B, int T, int control, int method);
+/* Diagnostic only: how many launches of that solve kernel one call with this batch makes (a batch that does not fit one
+ * residency is walked in chunks: e.g. 256 B-cell trajectories = two launches of k1_solve_adj3c).  op = PHX_OP_ODEINT or
+ * PHX_OP_ADJOINT; 0 when no plan exists.  bench.py multiplies per-launch profile figures with it. */
+int phx_debug_solve_launches(int op, int N, int H, int B, int T, int control, int method);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ EXPORTS = ("phx_abi_version", "phx_status_string", "phx_device_cus", "phx_worksp
            "phx_prior_targets", "phx_hill_rhs", "phx_hill_simulate", "phx_prior_mse", "phx_debug_adjoint_kernel",
            "phx_odeint_calls_workspace_bytes", "phx_weight_image_bytes", "phx_pack_weight_images", "phx_prior_targets_sell",
            "phx_debug_adjoint_kernel_m", "phx_prior_z_bytes", "phx_prior_mse_save", "phx_prior_vjp_saved",
-           "phx_layout_params", "phx_debug_forward_kernel_m", "phx_debug_queue_kernel_events")
+           "phx_layout_params", "phx_debug_forward_kernel_m", "phx_debug_queue_kernel_events", "phx_debug_solve_launches")
 
 OP_RHS_FORWARD, OP_RHS_VJP, OP_ODEINT, OP_ADJOINT = 0, 1, 2, 3
 METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "dopri5": 3}
@@ -97,6 +97,7 @@ def load():
     lib.phx_pack_weight_images.argtypes = [C.POINTER(PhxParams), vp, vp]
     lib.phx_layout_params.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     lib.phx_debug_forward_kernel_m.argtypes = [C.c_int] * 6
+    lib.phx_debug_solve_launches.argtypes = [C.c_int] * 7
     assert lib.phx_abi_version() == 7
     _LIB = lib
     return lib

@@ -1418,6 +1418,22 @@ int phx_debug_forward_kernel_m(int N, int H, int B, int T, int control, int meth
     return pick_chunk_v1(N, H, B, T, control, false) > 0 ? 1 : 0;
 }
 
+int phx_debug_solve_launches(int op, int N, int H, int B, int T, int control, int method)
+{
+    if (N <= 0 || H <= 0 || B <= 0 || T < 0 || (op != PHX_OP_ODEINT && op != PHX_OP_ADJOINT)) return 0;
+    int chunk = 0;
+    if (op == PHX_OP_ADJOINT) {
+        if ((chunk = adj3_chunk(N, H, B, T, control, method)) <= 0 && (chunk = adj3c_chunk(N, H, B, T, control, method)) <= 0 &&
+            (chunk = adj2_chunk(N, H, B, T, control)) <= 0)
+            chunk = pick_chunk_v1(N, H, B, T, control, true);
+    } else {
+        if ((chunk = fwd3_chunk(N, H, B, T, control, method)) <= 0 && (chunk = fwd3c_chunk(N, H, B, T, control, method)) <= 0)
+            chunk = pick_chunk_v1(N, H, B, T, control, false);
+    }
+    if (chunk <= 0) return 1;   // the VALU engine takes any batch in one launch
+    return (B + chunk - 1) / chunk;
+}
+
 size_t phx_workspace_bytes(int op, int N, int H, int B, int T)
 {
     if (N <= 0 || H <= 0 || B <= 0 || T < 0) return 0;

@@ -129,3 +129,40 @@ def test_no_wide_buffer_store_has_its_data_registers_overwritten_at_once():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")] + listings,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+def test_a_failed_solve_forgets_every_vouched_workspace():
+    """after a launch that ended in an error (above all PHX_ERR_SYNC_TIMEOUT, whose bail-out leaves the
+    exchange-set parity / `started` counters of the workspace header undefined) no cached workspace may be vouched for:
+    `raise_for_status` clears the `ws_keep` bookkeeping, so the next solve fills its exchange buffers again."""
+    from phoenix_amd import engine
+    engine._ws_last[(0, 0, 1)] = ("some", "plan")
+    engine.raise_for_status(torch.zeros(2, 3, dtype=torch.int32))        # all OK: nothing happens
+    assert engine._ws_last
+    with pytest.raises(AssertionError, match="max_num_steps"):
+        engine.raise_for_status(torch.tensor([[0, 0, 0], [0, 1, 0]], dtype=torch.int32))   # the reference's assert, rk_common.py:154
+    assert not engine._ws_last
+    engine._ws_last[(0, 0, 1)] = ("some", "plan")
+    with pytest.raises(RuntimeError, match="trajectory 2"):
+        engine.raise_for_status(torch.tensor([0, 0, 6], dtype=torch.int32))                # a launch-level failure
+    assert not engine._ws_last
+
+
+def test_odeint_on_a_differentiable_odenet_is_routed_to_the_adjoint(monkeypatch):
+    """`odeint` (odeint.py:30-74) returns an autograd-tracked solution in the reference; here a call whose inputs require
+    grad goes through `odeint_adjoint` (checked without a GPU by intercepting it), a call under no_grad does not."""
+    import phoenix_amd
+    import sys
+    od = sys.modules["phoenix_amd.odeint"]          # (the package re-exports the function under the module's name)
+    net = phoenix_amd.ODENet("cpu", 16, neurons=4)
+    y0, t = torch.rand(2, 1, 16), torch.tensor([0.0, 1.0])
+    seen = {}
+
+    def fake_adjoint(func, y0_, t_, **kw):
+        seen.update(kw)
+        return "routed"
+
+    monkeypatch.setattr(od, "odeint_adjoint", fake_adjoint)
+    assert phoenix_amd.odeint(net, y0, t, method="rk4") == "routed" and seen["_via_odeint"] and seen["method"] == "rk4"
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path|must live on the GPU"):
+        phoenix_amd.odeint(net, y0, t)          # not routed: the plain forward solve (which has no CPU path)
