@@ -46,7 +46,9 @@ bool plan_adj3(int N, int H, int B, int T, int control, int method, D1 *out)
             const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
             const bool helpers = ntg < slots;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
-            const size_t cb = ctl3_bytes(Bt, ntg);
+            // (+ the LDS of the block-split combine where the batch is that small: v3_split_parts)
+            const size_t cb = ((ctl3_bytes(Bt, ntg) + 15) & ~(size_t)15) +
+                              (v3_split_parts(TG, NW, TPW, ntg) > 1 ? v3_comb_bytes(NW, 4 * HT) : 0);
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
             const char *enb = getenv("PHX_V3_NB");   // experiment: smallest gene tile to consider
@@ -111,7 +113,11 @@ Layout3 make_layout3(const D1 &d, bool grads)
     return L;
 }
 
-size_t lds_bytes_adj3(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ctl3_bytes(d.Bt, d.ntg); }
+size_t lds_bytes_adj3(const D1 &d)
+{
+    return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ((ctl3_bytes(d.Bt, d.ntg) + 15) & ~(size_t)15) +
+           (v3_split_parts(d.TG, d.NW, d.TPW, d.ntg) > 1 ? v3_comb_bytes(d.NW, 4 * d.HT) : 0);
+}
 
 }  // namespace
 
@@ -199,8 +205,11 @@ int adj3_run(const phx_params *p, const double *t_all, int B, int T, const phx_s
         // HALF: the last hidden tile has at most 8 live rows (H <= 40 with three tiles; rho16 in phx_mfma_v3common.inc)
         const char *eh = getenv("PHX_V3_HALF");   // diagnostic: 0 = full last tile also where half of it is padding
         const bool half = p->H <= 16 * (d1.HT - 1) + 8 && !(eh && eh[0] == '0');
-        const void *fn = half ? reinterpret_cast<const void *>(k1_solve_adj3<3, true>)
-                              : reinterpret_cast<const void *>(k1_solve_adj3<3, false>);
+        const bool split = v3_split_parts(d1.TG, d1.NW, d1.TPW, d1.ntg) > 1;   // small batch: the waves of a tile split its blocks
+        const void *fn = split ? (half ? reinterpret_cast<const void *>(k1_solve_adj3<3, true, true>)
+                                       : reinterpret_cast<const void *>(k1_solve_adj3<3, false, true>))
+                               : (half ? reinterpret_cast<const void *>(k1_solve_adj3<3, true, false>)
+                                       : reinterpret_cast<const void *>(k1_solve_adj3<3, false, false>));
         if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;
         // the workgroups of a launch wait for each other's rows: refuse a grid the device cannot hold at once
         if (!fits_resident(fn, 64 * d1.NW, lds, d1.TG * d1.G)) return PHX_ERR_LAUNCH;

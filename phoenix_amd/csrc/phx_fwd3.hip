@@ -47,7 +47,9 @@ bool plan_fwd3(int N, int H, int B, int T, int control, int method, D1 *out)
             const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
             const bool helpers = ntg < slots;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
-            const size_t cb = ctlf3_bytes(Bt, ntg);
+            // (+ the LDS of the block-split combine where the batch is that small: v3_split_parts)
+            const size_t cb = ((ctlf3_bytes(Bt, ntg) + 15) & ~(size_t)15) +
+                              (v3_split_parts(TG, NW, TPW, ntg) > 1 ? v3_comb_bytes(NW, 2 * HT) : 0);
             if (cb + blkbytes > LDS_BUDGET) continue;
             const int NBmax = (int)std::min<size_t>((LDS_BUDGET - cb) / blkbytes, 8);
             const char *enb = getenv("PHX_V3_NB");   // experiment: smallest gene tile to consider
@@ -104,7 +106,11 @@ LayoutF3 make_layout_f3(const D1 &d)
     return L;
 }
 
-size_t lds_bytes_fwd3(const D1 &d) { return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ctlf3_bytes(d.Bt, d.ntg); }
+size_t lds_bytes_fwd3(const D1 &d)
+{
+    return (size_t)blk_floats_ch(d.HT, d.H) * 4 * d.NB + ((ctlf3_bytes(d.Bt, d.ntg) + 15) & ~(size_t)15) +
+           (v3_split_parts(d.TG, d.NW, d.TPW, d.ntg) > 1 ? v3_comb_bytes(d.NW, 2 * d.HT) : 0);
+}
 
 }  // namespace
 
@@ -192,7 +198,9 @@ int fwd3_run(const phx_params *p, const float *y0_all, const double *t_all, int 
         // HALF: the last hidden tile has at most 8 live rows (H <= 40 with three tiles; rho16 in phx_mfma_v3common.inc)
         const char *eh = getenv("PHX_V3_HALF");   // diagnostic: 0 = full last tile also where half of it is padding
         const bool half = p->H <= 16 * (d1.HT - 1) + 8 && !(eh && eh[0] == '0');
-        const int lrc = half ? launch(k1_solve_fwd3<3, 256, true>) : launch(k1_solve_fwd3<3, 256, false>);
+        const bool split = v3_split_parts(d1.TG, d1.NW, d1.TPW, d1.ntg) > 1;   // small batch: the waves of a tile split its blocks
+        const int lrc = split ? (half ? launch(k1_solve_fwd3<3, 256, true, true>) : launch(k1_solve_fwd3<3, 256, false, true>))
+                              : (half ? launch(k1_solve_fwd3<3, 256, true, false>) : launch(k1_solve_fwd3<3, 256, false, false>));
         if (lrc != PHX_OK) return lrc;
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;
     }
