@@ -228,6 +228,42 @@ def test_g5_training_step(pa, dev, method, lam):
         assert d.size == 0 or d.max() < 1e-5, k
 
 
+@pytest.mark.parametrize("N,H", [(350, 40), (777, 64), (1100, 131), (500, 200), (333, 256)])
+def test_layout_params_and_pack_weight_images_write_the_same_images(pa, dev, N, H):
+    """The two producers of the packed LDS weight images promise the same bytes (include/phoenix_hip.h): `phx_layout_params`
+    (what the Python path calls once per parameter version, straight from W_alpha [N, 2H]) and `phx_pack_weight_images` (what a C
+    caller without the former, and the library itself when `phx_params.wimg` is NULL, use).  Compared: every live column of
+    every row of every (gene block, hidden chunk) image incl. the zero rows and relu(gene_multipliers), for one- and
+    two-chunk layers and a ragged last gene block; and WaT against Wa.t().  (The 33rd float of a row is padding nobody reads.)"""
+    import ctypes as C
+    from phoenix_amd import _lib, engine
+    net = make_net(pa, dev, rand_params(N, H, seed=N + H))
+    P = engine.Params(*pa.odenet.params_of(net))                      # runs phx_layout_params
+    torch.cuda.synchronize()
+    nbytes = _lib.load().phx_weight_image_bytes(N, H)
+    assert nbytes > 0 and P.wimg is not None and P.wimg.numel() == nbytes
+    other = torch.full((nbytes,), 0x7F, dtype=torch.uint8, device=dev)
+    assert _lib.load().phx_pack_weight_images(C.byref(P.c), C.c_void_p(other.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    HC = (H + 127) // 128
+    Hc = (H + HC - 1) // HC
+    HT = 3 if Hc <= 48 else (7 if (HC > 1 and Hc <= 112) else 8)       # solve_ht (phx_engine.hip)
+    BF = (((4 * Hc + (16 * HT - Hc)) * 33 + 32) + 3) & ~3              # blk_floats_ch
+    nblk = (N + 31) // 32
+    a = P.wimg.view(torch.float32).reshape(nblk, HC, BF).cpu().numpy()
+    b = other.view(torch.float32).reshape(nblk, HC, BF).cpu().numpy()
+    for ch in range(HC):
+        hc = min(Hc, H - ch * Hc)
+        rows = 4 * hc + (16 * HT - hc)
+        ia = a[:, ch, :rows * 33].reshape(nblk, rows, 33)[:, :, :32]
+        ib = b[:, ch, :rows * 33].reshape(nblk, rows, 33)[:, :, :32]
+        assert np.array_equal(ia, ib), (ch, "weight rows")
+        assert np.array_equal(a[:, ch, BF - 32:], b[:, ch, BF - 32:]), (ch, "relu(g)")
+        assert not ia[:, 4 * hc:].any(), (ch, "zero rows")
+    assert torch.equal(P.WaT, net.net_alpha_combine.linear_out.weight.detach().t().contiguous())
+
+
 def test_parameter_cache_follows_the_optimizer(pa, dev):
     """The engine caches its layout of the parameters (transposed W_alpha, packed LDS weight images) per parameter
     version.  Five SGD steps of the reference's training_step with the cache, and the same five steps with the cache
