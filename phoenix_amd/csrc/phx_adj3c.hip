@@ -44,6 +44,7 @@ bool plan_adj3c(int N, int H, int B, int T, int control, int method, D1 *out, in
     const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4;
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     const int fnb = env_int("PHX_V3C_NB", 0), ftpw = env_int("PHX_V3C_TPW", 0), fres = env_int("PHX_V3C_RES", -1);
+    const int fhb = env_int("PHX_V3C_HB", -1);
     // at most FOUR (tile, block) slots per wave: the eight-slot instantiation needs more than the 512 registers (3 460 spilled,
     // and this compiler fails on its <8, false> form); a batch that needs more slots runs as several launches (pick_chunk)
     const int maxslots = std::min(4, std::max(1, env_int("PHX_V3C_SLOTS", 4)));
@@ -73,11 +74,16 @@ bool plan_adj3c(int N, int H, int B, int T, int control, int method, D1 *out, in
                     best.nvec = NVEC_ADJ3C; best.BN = (long long)B * N; best.HC = HC; best.Hc = Hc;
                     best.Bcall = 0; best.cntN = (long long)B * N; best.res = res ? 1 : 0;
                     const int nslot = TPW * NB;
+                    // half-block gene tiles (plan_fwd3c): one slot per wave and room for twice the workgroups
+                    // (measured: -4..-37 % of a launch wherever twice the workgroups fit the chip)
+                    const bool hb_fits = nslot == 1 && res && (long long)TG * G * 2 <= cus && cb + HSA_BYTES + 16 + blkbytes * HC <= LDS_BUDGET;
+                    best.hb = (hb_fits && fhb != 0) ? 1 : 0;
                     best_nbt = nslot <= 1 ? 1 : 4;
                 }
             }
         }
     if (best_cost < 0) return false;
+    if (best.hb) best.G = 2 * best.nblk;
     *out = best;
     if (nbt_out) *nbt_out = best_nbt;
     return true;
@@ -124,7 +130,7 @@ Layout3C make_layout3c(const D1 &d, bool grads)
 
 size_t lds_bytes_adj3c(const D1 &d)
 {
-    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + ctl3c_bytes(d.Bt, d.ntg);
+    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + (d.hb ? hsa_offset(d.Bt, d.ntg) + HSA_BYTES : ctl3c_bytes(d.Bt, d.ntg));
 }
 
 }  // namespace
@@ -150,7 +156,7 @@ int adj3c_profile_region(int N, int H, int B, int T, int control, size_t *offset
     if (!plan_adj3c(N, H, B, T, control, PHX_DOPRI5, &d1, nullptr)) return PHX_ERR_BAD_ARG;
     *offset = make_layout3c(d1, true).prof;
     *n_workgroups = d1.TG * d1.G;
-    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res; }
+    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb; }
     return PHX_OK;
 }
 
@@ -208,11 +214,13 @@ int adj3c_run(const phx_params *p, const double *t_all, int B, int T, const phx_
                            d1.Hc, blk_floats_ch(d1.HT, d1.Hc));
         const bool half = d1.Hc <= 40;   // every chunk's last tile has at most 8 live rows (rho16, phx_mfma_v3common.inc)
         const void *fn;
-        switch (nbt * 2 + (half ? 1 : 0)) {
-        case 3: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, true>); break;
-        case 2: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, false>); break;
-        case 9: fn = reinterpret_cast<const void *>(k1_solve_adj3c<4, true>); break;
-        case 8: fn = reinterpret_cast<const void *>(k1_solve_adj3c<4, false>); break;
+        switch (nbt * 2 + (half ? 1 : 0) + (d1.hb ? 32 : 0)) {
+        case 35: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, true, true>); break;
+        case 34: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, false, true>); break;
+        case 3: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, true, false>); break;
+        case 2: fn = reinterpret_cast<const void *>(k1_solve_adj3c<1, false, false>); break;
+        case 9: fn = reinterpret_cast<const void *>(k1_solve_adj3c<4, true, false>); break;
+        case 8: fn = reinterpret_cast<const void *>(k1_solve_adj3c<4, false, false>); break;
         default: return PHX_ERR_BAD_ARG;
         }
         if (!set_lds_fn(fn, lds)) return PHX_ERR_LAUNCH;

@@ -35,7 +35,8 @@ int env_int(const char *name, int dflt)
 // Hidden chunks: HC = ceil(H / 48) chunks of Hc = ceil(H / HC) rows, three 16-row tiles each (120 -> 3 x 40, 200 -> 5 x 40).
 // (NW, TPW, NB): one wave per SIMD, gene tiles of 1 / 2 / 4 / 8 blocks, at most 8 (tile, block) slots per wave (the kernel
 // keeps their partial sums in registers); all chunks LDS resident when they fit, else one re-staged slot.  Cost: the
-// per-wave MFMA work first, then the exchange volume (members per group).
+// per-wave MFMA work first, then the exchange volume (members per group).  A plan of ONE slot per wave whose workgroups
+// leave half the chip idle takes HALF-BLOCK gene tiles (hb: twice the workgroups, half the sweep work each).
 bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, int *nbt_out)
 {
     const int cus = num_cus();
@@ -44,6 +45,7 @@ bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, in
     const size_t blkbytes = (size_t)blk_floats_ch(HT, Hc) * 4;
     const int nblk = (N + 31) / 32, ntt = (B + 15) / 16;
     const int fnb = env_int("PHX_V3C_NB", 0), ftpw = env_int("PHX_V3C_TPW", 0), fres = env_int("PHX_V3C_RES", -1);
+    const int fhb = env_int("PHX_V3C_HB", -1);
     long long best_cost = -1;
     D1 best{};
     int best_nbt = 0;
@@ -70,11 +72,16 @@ bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, in
                     best.nvec = NVEC_FWD3C; best.BN = (long long)B * N; best.HC = HC; best.Hc = Hc;
                     best.Bcall = 0; best.cntN = (long long)B * N; best.res = res ? 1 : 0;
                     const int nslot = TPW * NB;
+                    // measured (round 5, H = 120 / 200, 8..220 gene blocks, 16..128 trajectories): -9..-33 % of a launch while
+                    // the workgroups cover at most half the chip, +5..+24 % beyond (tools/v3c_check.py hbgrid)
+                    const bool hb_fits = nslot == 1 && res && (long long)TG * G * 2 <= cus && cb + HSF_BYTES + 16 + blkbytes * HC <= LDS_BUDGET;
+                    best.hb = (hb_fits && fhb != 0 && (fhb == 1 || (long long)TG * G * 4 <= cus)) ? 1 : 0;
                     best_nbt = nslot <= 1 ? 1 : 8;   // (unused slots of the eight-slot form cost a scalar branch each)
                 }
             }
         }
     if (best_cost < 0) return false;
+    if (best.hb) best.G = 2 * best.nblk;
     *out = best;
     if (nbt_out) *nbt_out = best_nbt;
     return true;
@@ -115,7 +122,7 @@ LayoutF3C make_layout_f3c(const D1 &d)
 
 size_t lds_bytes_fwd3c(const D1 &d)
 {
-    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + ctlf3c_bytes(d.Bt, d.ntg);
+    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + (d.hb ? hsf_offset(d.Bt, d.ntg) + HSF_BYTES : ctlf3c_bytes(d.Bt, d.ntg));
 }
 
 }  // namespace
@@ -141,7 +148,7 @@ int fwd3c_profile_region(int N, int H, int B, int T, int control, size_t *offset
     if (!plan_fwd3c(N, H, B, T, control, PHX_DOPRI5, &d1, nullptr)) return PHX_ERR_BAD_ARG;
     *offset = make_layout_f3c(d1).prof;
     *n_workgroups = d1.TG * d1.G;
-    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res; }
+    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb; }
     return PHX_OK;
 }
 
@@ -202,11 +209,13 @@ int fwd3c_run(const phx_params *p, const float *y0_all, const double *t_all, int
         };
         const bool half = d1.Hc <= 40;   // every chunk's last tile has at most 8 live rows (rho16, phx_mfma_v3common.inc)
         int lrc;
-        switch (nbt * 2 + (half ? 1 : 0)) {
-        case 3: lrc = launch(k1_solve_fwd3c<1, true>); break;
-        case 2: lrc = launch(k1_solve_fwd3c<1, false>); break;
-        case 17: lrc = launch(k1_solve_fwd3c<8, true>); break;
-        default: lrc = launch(k1_solve_fwd3c<8, false>); break;
+        switch (nbt * 2 + (half ? 1 : 0) + (d1.hb ? 32 : 0)) {
+        case 35: lrc = launch(k1_solve_fwd3c<1, true, true>); break;
+        case 34: lrc = launch(k1_solve_fwd3c<1, false, true>); break;
+        case 3: lrc = launch(k1_solve_fwd3c<1, true, false>); break;
+        case 2: lrc = launch(k1_solve_fwd3c<1, false, false>); break;
+        case 17: lrc = launch(k1_solve_fwd3c<8, true, false>); break;
+        default: lrc = launch(k1_solve_fwd3c<8, false, false>); break;
         }
         if (lrc != PHX_OK) return lrc;
         if (hipGetLastError() != hipSuccess) return PHX_ERR_LAUNCH;

@@ -1126,6 +1126,48 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
             assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
+@pytest.mark.parametrize("N,H,B", [(322, 120, 37), (500, 200, 20), (250, 120, 70), (777, 120, 12)])
+def test_half_block_gene_tiles_and_helper_waves_vs_oracle(pa, dev, oracle, monkeypatch, N, H, B):
+    """Chunked third-generation kernels, HALF-BLOCK gene tiles (two workgroups per 32-gene block):
+    three tiles and a last block whose second half is padding only (322 genes), two tiles with one helper wave each
+    (B = 20), two batch groups with at most 16 members (250 genes), one tile with three helper waves (B = 12) -- each
+    against the oracle, and against whole-block tiles (PHX_V3C_HB=0: same steps, other summation order)."""
+    import ctypes as C
+    from phoenix_amd import _lib
+    p = rand_params(N, H, seed=3 * N + H, std=0.03)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(9)
+    y0 = r.rand(B, N).astype(np.float32)
+    t = np.stack([np.array([0.0, 0.5 + 0.01 * (b % 7)]) for b in range(B)]).astype(np.float32)
+    G = r.randn(B, 2, N).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
+    out = {}
+    for hb in ("1", "0"):
+        monkeypatch.setenv("PHX_V3C_HB", hb)
+        lib = _lib.load()
+        plan = (C.c_int * 6)()
+        off, nwg = C.c_size_t(0), C.c_int(0)
+        for op in (_lib.OP_ODEINT, _lib.OP_ADJOINT):
+            assert lib.phx_debug_profile_region(op, N, H, B, 2, _lib.CTRL_PER_TRAJECTORY, C.byref(off), C.byref(nwg), plan) == 0
+            assert (plan[5] % 10) // 2 == int(hb), (op, list(plan))   # the half-block form runs where the test says it does
+        for q in net.parameters():
+            q.grad = None
+        y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+        sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+        got = sol.detach().cpu().numpy().reshape(2, B, N).transpose(1, 0, 2)
+        assert relerr(got, ref) < TOL_DOPRI, hb
+        (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(2, B, 1, N).copy()).to(dev)).sum().backward()
+        assert grad_err(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD, hb
+        gg = grads_of(net)
+        for k in KEYS:
+            assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, hb)
+        out[hb] = (got, gg)
+    assert relerr(out["1"][0], out["0"][0]) < TOL_DOPRI
+    for k in KEYS:
+        assert relerr(out["1"][1][k], out["0"][1][k]) < TOL_DOPRI_GRAD, k
+
+
 @pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 1100), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100)])
 def test_prior_backward_from_saved_hidden_rows_equals_recomputation(pa, dev, N, H, K):
     """phx_prior_mse_save + phx_prior_vjp_saved (the forward chain's hidden rows kept for the backward) give the bits of

@@ -17,7 +17,7 @@ from phoenix_amd import _lib, engine  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 dev = torch.device("cuda:0")
-ENVK = ("PHX_V3C", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
+ENVK = ("PHX_V3C", "PHX_V3C_HB", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
 
 
 def relerr(a, b):
@@ -167,6 +167,9 @@ if __name__ == "__main__":
     if mode in ("all", "quick"):
         # resident chunk slots (small gene tiles)
         case("H=120 single step", 777, 120, 21, grids(21, 0.0, 0.01), 0.03)
+        case("H=120 half-block tiles, empty half", 322, 120, 37, grids(37, 0.0, 0.6, spread=0.002), 0.03)
+        case("H=120 whole-block tiles (HB=0)", 322, 120, 37, grids(37, 0.0, 0.6, spread=0.002), 0.03, env={"PHX_V3C_HB": "0"})
+        case("H=200 half-block tiles, groups", 500, 200, 100, grids(100, 0.0, 0.3), 0.02)
         case("H=120 multi step", 777, 120, 21, grids(21, 0.0, 0.5, spread=0.05), 0.03)
         case("H=64 three intervals", 350, 64, 64, grids(64, 0.0, 0.9, T=4, spread=0.01), 0.04)
         case("H=100 ragged, groups", 350, 100, 150, grids(150, 0.0, 0.3, spread=0.002), 0.04)
@@ -181,6 +184,24 @@ if __name__ == "__main__":
              env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "4", "PHX_V3C_TPW": "2"})
         case("H=200 restaged TPW=4 NB=2", 900, 200, 200, grids(200, 0.0, 0.2, spread=0.001), 0.02,
              env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "2", "PHX_V3C_TPW": "4"}, with_oracle=False)
+    if mode == "hb":        # half-block gene tiles against whole-block ones
+        timing("yeast N=2000 H=120 B=23", 2000, 120, 23, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
+        timing("yeast N=2000 H=120 B=4", 2000, 120, 4, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
+        timing("yeast N=2000 H=120 B=128", 2000, 120, 128, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
+        timing("N=350 H=100 B=64", 350, 100, 64, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}])
+    if mode == "hbgrid":    # where half-block tiles pay: gene blocks x trajectory tiles
+        for N in (250, 350, 600, 800, 1000, 2000, 3500):
+            for B in (16, 32, 48, 64, 128):
+                timing("N=%d H=120 B=%d" % (N, B), N, 120, B, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {"PHX_V3C_HB": "1"}], reps=3)
+        for N in (350, 2000):
+            for B in (16, 64):
+                timing("N=%d H=200 B=%d" % (N, B), N, 200, B, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {"PHX_V3C_HB": "1"}], reps=3)
+    if mode == "plans":     # plan alternatives of the chunked kernels at the two bench shapes (environment overrides)
+        timing("yeast N=2000 H=120 B=23", 2000, 120, 23, [0.0, 5.0], 0.05, 0.95,
+               [{}, {"PHX_V3C_NB": "2"}, {"PHX_V3C_NB": "2", "PHX_V3C_RES": "0"}, {"PHX_V3C_RES": "0"}], yrange=(-0.3, 0.9))
+        timing("yeast N=2000 H=120 B=4", 2000, 120, 4, [0.0, 5.0], 0.05, 0.95, [{}, {"PHX_V3C_NB": "2"}], yrange=(-0.3, 0.9))
+        timing("bcell N=14691 H=200 B=256", 14691, 200, 256, [0.0, 1.0], 0.05, 0.95,
+               [{}, {"PHX_V3C_NB": "2"}, {"PHX_V3C_NB": "8"}, {"PHX_V3C_TPW": "1"}], reps=3)
     if mode in ("all", "time"):
         timing("yeast N=2000 H=120 B=23", 2000, 120, 23, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C": "0"}, {}], yrange=(-0.3, 0.9))
         timing("bcell N=14691 H=200 B=256", 14691, 200, 256, [0.0, 1.0], 0.05, 0.95,
