@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: per-segment time of the v1 persistent kernels (PHX_PROF=1), averaged over workgroups.
-usage: PHX_PROF=1 python tools/prof_segments.py [workload] [fwd|adj] [trajectories]
+usage: PHX_PROF=1 python tools/prof_segments.py [workload | N,H,B[,t1]] [fwd|adj] [trajectories]
 PHX_PROF=2 (per-block timers inside the sweeps of the second / third-generation kernels) needs the diagnostic build of the library
 (the marks are compiled out of the regular one: they cost 1.5-2.3 % of a launch): `python -m phoenix_amd.build --prof`
 here, or it is built on first use; this script then loads libphoenix_prof.so."""
@@ -20,7 +20,12 @@ if os.environ["PHX_PROF"] == "2" and "PHX_LIB" not in os.environ:
 import bench  # noqa: E402
 from phoenix_amd import _lib, engine  # noqa: E402
 
-wl = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "breast"])
+_w = sys.argv[1] if len(sys.argv) > 1 else "breast"
+if "," in _w:      # a shape of one's own: N,H,B[,t1]  (dopri5, t = [0, t1])
+    _p = _w.split(",")
+    wl = dict(N=int(_p[0]), H=int(_p[1]), B=int(_p[2]), method="dopri5", t=[0.0, float(_p[3]) if len(_p) > 3 else 1.0], desc=_w)
+else:
+    wl = dict(bench.WORKLOADS[_w])
 if len(sys.argv) > 3:
     wl["B"] = int(sys.argv[3])
 which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
