@@ -669,6 +669,22 @@ def main(args):
                         ms_ref = (time.perf_counter() - t0) / reps * 1e3
                     finally:
                         engine.set_status_mode("immediate")
+                    # the same step recorded into ONE HIP graph (phoenix_amd.GraphedStep): what it costs once the host's
+                    # Python / launch work is out of the way (at this size the eager step is host bound on slower hosts)
+                    ms_graph = None
+                    try:
+                        gstep = phoenix_amd.GraphedStep(lambda: one_step(net, ys, ts_, Gs, wl["method"], 1))
+                        for _ in range(10):
+                            gstep()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(reps):
+                            gstep()
+                        torch.cuda.synchronize()
+                        ms_graph = (time.perf_counter() - t0) / reps * 1e3
+                        gstep.check_status()
+                    except Exception as exc:   # noqa: BLE001
+                        ms_graph = repr(exc)[:160]
                     solr, str_, nfr, _ = engine.solve_forward(p, ys.reshape(Bref, N).contiguous(), ts_.double().contiguous(),
                                                               wl["method"], _lib.CTRL_PER_TRAJECTORY, 1e-7, 1e-9, True, True)
                     _, _, stb_, nbr, _ = engine.solve_adjoint(p, ts_.double().contiguous(), solr,
@@ -679,7 +695,7 @@ def main(args):
                     bytes_r = (nf_r / Bref) * (4 * P + 8 * Bref * N) + (nb_r / Bref) * (8 * P + 16 * Bref * N)
                     flop_r = (nf_r / Bref) * 8.0 * Bref * N * H + (nb_r / Bref) * 24.0 * Bref * N * H
                     out["extra"]["reference_batch"] = {
-                        "trajectories": Bref, "control": "per-sample", "ms_per_step": ms_ref,
+                        "trajectories": Bref, "control": "per-sample", "ms_per_step": ms_ref, "graph_ms_per_step": ms_graph,
                         "value": (nf_r + nb_r) * N / (ms_ref * 1e-3), "unit": "gene*trajectory RHS evals/s",
                         "nfe_forward": nf_r, "nfe_augmented": nb_r,
                         "roofline": {"bound": "hbm", "achieved": bytes_r / (ms_ref * 1e-3) / 1e9, "peak": PEAK_HBM,

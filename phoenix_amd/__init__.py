@@ -6,6 +6,7 @@ from .odeint import SOLVERS, odeint, odeint_adjoint, odeint_calls, odeint_per_sa
 from .odenet import ODENet  # noqa: F401
 from .engine import check_pending_status, set_status_mode  # noqa: F401
 from .training import training_step  # noqa: F401
+from .graphs import GraphedStep  # noqa: F401
 from .data import DataHandler, readcsv, writecsv  # noqa: F401
 from .prior import PriorMatrix, prior_targets, read_prior_matrix  # noqa: F401
 from .analysis import gene_influence_scores  # noqa: F401

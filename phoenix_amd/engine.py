@@ -21,8 +21,23 @@ def _require_gpu(x, name):
                         "reference's configs" % (name, x.dtype))
 
 
+# The host side of a step is a few hundred microseconds of Python, which is what a small-batch step costs on a slow host
+# (17 trajectories at the breast-cancer shape: 0.32 ms of kernels): the current stream and the plan switches are read
+# through the cheapest route there is (torch.cuda.current_stream() builds a Stream object through four Python frames, 8 us;
+# os.environ.get encodes and decodes, 0.8 us per switch, and a solve reads all of them several times).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _stream_raw(device_index=None):
+    """handle (an int) of the current HIP stream of `device_index` (default: the current device)"""
+    if _raw_stream is None or _raw_device is None:
+        return torch.cuda.current_stream(device_index).cuda_stream
+    return _raw_stream(_raw_device() if device_index is None else device_index)
+
+
 def _stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_stream_raw())
 
 
 _ws_bytes = {}
@@ -31,10 +46,27 @@ _PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD"
              "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_V3C_HB")
 
 
+_PLAN_ENV_B = tuple(os.fsencode(k) for k in _PLAN_ENV)
+_env_data = getattr(os.environ, "_data", None)
+
+
+def _plan_env():
+    """the values of the plan switches (part of every plan / workspace key: the tests and tools flip them between calls)"""
+    if isinstance(_env_data, dict) and os.name == "posix":
+        return tuple(map(_env_data.get, _PLAN_ENV_B))     # bytes or None: only compared with itself
+    return tuple(os.environ.get(k) for k in _PLAN_ENV)
+
+
 # phx_solve_opts.ws_keep: what the previous solve on a cached workspace was (plan key), so that the next identical one can
 # vouch for the workspace and the library skips the fill of its exchange buffers (the third-generation kernels alternate
 # between two sets and clean the idle one themselves).  Any other use drops the entry: the next call fills as usual.
 _ws_last = {}
+
+
+def forget_params():
+    """drops the cached engine layouts of parameter tensors (`params_cached`): for a caller that changed parameters behind
+    PyTorch's version counters -- a replayed graph that contains the optimizer step does"""
+    _params_cache.clear()
 
 
 def forget_workspaces():
@@ -45,7 +77,7 @@ def forget_workspaces():
 
 def _workspace(op, N, H, B, T, device, calls=1):
     # the size query re-plans the launch on the host: remembered per shape (and per diagnostic switch setting)
-    key = (op, N, H, B, T, calls) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    key = (op, N, H, B, T, calls) + _plan_env()
     nbytes = _ws_bytes.get(key)
     if nbytes is None:
         if calls > 1:
@@ -56,7 +88,7 @@ def _workspace(op, N, H, B, T, device, calls=1):
         else:
             nbytes = _lib.load().phx_workspace_bytes(op, N, H, B, T)
         _ws_bytes[key] = nbytes
-    key = (device.index, torch.cuda.current_stream().cuda_stream, op)
+    key = (device.index, _stream_raw(device.index), op)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -98,12 +130,15 @@ class Params:
                                 self.N, self.H, self.wimg.data_ptr() if nbytes else None)
         # ready event, unconditionally: the contiguous / transposed copies above are written on this stream too
         self._ready_stream = torch.cuda.current_stream()
+        self._ready_raw = self._ready_stream.cuda_stream
         self._ready_event = torch.cuda.Event()
         self._ready_event.record()
 
     def on_current_stream(self):
         """a call on another stream than the one that laid these parameters out waits for the layout (copies and
         packed images) and keeps their memory alive for that stream"""
+        if _stream_raw(self.device.index) == self._ready_raw:
+            return self
         cur = torch.cuda.current_stream()
         if cur != self._ready_stream:
             cur.wait_event(self._ready_event)
@@ -180,6 +215,7 @@ def _raise(status, worst):
 
 _status_mode = "immediate"
 _pending = []          # (event, pinned status copy [L, B]) of solves whose status has not been read yet
+captured_status = []   # "captured" mode: the device status blocks of the solves issued since the mode was set
 
 
 def set_status_mode(mode):
@@ -187,10 +223,12 @@ def set_status_mode(mode):
     the end of backward(), as the reference raises its asserts synchronously.  "deferred": the status block is copied to
     pinned host memory behind the backward kernel and checked at a later engine call (or `check_pending_status(True)`)
     once its event has completed -- the same AssertionError, raised up to two engine calls late, and the host no longer
-    idles the GPU between steps."""
+    idles the GPU between steps.  "captured": nothing is read at all -- every status block stays on the device and is
+    appended to `captured_status`; for steps recorded into a HIP graph (phoenix_amd.graphs.GraphedStep), whose caller
+    reads them after a replay (`check_captured_status`)."""
     global _status_mode
-    assert mode in ("immediate", "deferred")
-    if mode == "immediate":
+    assert mode in ("immediate", "deferred", "captured")
+    if mode != "deferred":
         check_pending_status(wait=True)
     _status_mode = mode
 
@@ -204,6 +242,9 @@ _free_host = {}        # (shape, dtype) -> pinned buffers of checked solves, reu
 
 def defer_status(status):
     """queue a device status block [L, B] (or [B]) for a later check"""
+    if _status_mode == "captured":
+        captured_status.append(status)
+        return
     key = (tuple(status.shape), status.dtype)
     pool = _free_host.setdefault(key, [])
     host = pool.pop() if pool else torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
@@ -215,6 +256,8 @@ def defer_status(status):
 
 def check_pending_status(wait=False):
     """raise for every queued solve that has finished (all of them with wait=True)"""
+    if _status_mode == "captured":
+        return                   # (event queries and synchronisation have no place inside a capture)
     while _pending:
         ev, host = _pending[0]
         if not wait and not ev.query():
@@ -228,10 +271,22 @@ def check_pending_status(wait=False):
         raise_for_status(host)
 
 
-def raise_for_status(status):
+def check_captured_status(blocks=None):
+    """reads the status blocks a captured step left on the device (default: `captured_status`) and raises like
+    `raise_for_status`; one device->host read per block, outside any capture"""
+    for st in (captured_status if blocks is None else blocks):
+        raise_for_status(st, _force=True)
+
+
+def raise_for_status(status, _force=False):
     """Maps per-trajectory solver status onto the reference's exceptions (rk_common.py:154,175-176,
     misc.py:114-115).  One device->host read.  `status` is [B], or [L, B] for L consecutive launches (the forward
-    and backward solve of a training step share one stats block): the earliest failing launch is reported."""
+    and backward solve of a training step share one stats block): the earliest failing launch is reported.
+    In "captured" status mode (a step being recorded into a graph, or one of its warm-up runs) the block is kept for
+    `check_captured_status` instead."""
+    if _status_mode == "captured" and status.is_cuda and not _force:
+        captured_status.append(status)
+        return
     if status.dim() == 1:
         status = status.unsqueeze(0)
     if not status.is_cuda and not bool(status.any()):
@@ -338,7 +393,7 @@ def _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, ca
 
 def _solve_call(op, pkey, device, call):
     """runs `call(ws_keep)` (the C entry point) and keeps the workspace bookkeeping of ws_keep"""
-    wkey = (device.index, torch.cuda.current_stream().cuda_stream, op)
+    wkey = (device.index, _stream_raw(device.index), op)
     keep = 1 if _ws_last.get(wkey) == pkey else 0
     _ws_last.pop(wkey, None)              # whatever happens below, the workspace is no longer in its previous state
     _check_call(call(keep))
@@ -360,7 +415,7 @@ def solve_forward(p, y0, t64, method, control, rtol, atol, t_per_sample, t_is_f3
         stats = torch.empty((3, B), dtype=torch.int32, device=y0.device)
     p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ODEINT, p.N, p.H, B, T, y0.device, calls)
-    pkey = (p.N, p.H, B, T, method, control, int(t_per_sample), calls) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    pkey = (p.N, p.H, B, T, method, control, int(t_per_sample), calls) + _plan_env()
 
     def call(keep):
         o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, calls, keep)
@@ -381,7 +436,7 @@ def solve_adjoint(p, t64, y_saved, grad_y, method, control, rtol, atol, t_per_sa
     grads = p.new_grads() if want_grads else None
     p.on_current_stream()
     ws, nb = _workspace(_lib.OP_ADJOINT, p.N, p.H, B, T, y_saved.device)
-    pkey = (p.N, p.H, B, T, method, control, int(t_per_sample), bool(want_grads)) + tuple(os.environ.get(k) for k in _PLAN_ENV)
+    pkey = (p.N, p.H, B, T, method, control, int(t_per_sample), bool(want_grads)) + _plan_env()
 
     def call(keep):
         o = _opts(method, control, rtol, atol, t_per_sample, t_is_f32, max_num_steps, 1, keep)

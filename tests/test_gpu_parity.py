@@ -1611,6 +1611,61 @@ def test_other_stream_and_mixed_time_directions(pa, dev, oracle):
 
 
 
+@pytest.mark.parametrize("N,H,B,method", [(350, 40, 17, "dopri5"), (600, 120, 5, "dopri5"), (350, 40, 64, "rk4")])
+def test_training_step_recorded_into_a_graph(pa, dev, N, H, B, method):
+    """phoenix_amd.GraphedStep: a step (parameter re-layout, forward solve, backward solve, gradient reduction, an SGD
+    update) recorded into ONE HIP graph replays to bitwise the eager step's parameters, with the solver status left on the
+    device; a step that fails raises from check_status() like the eager one."""
+    from phoenix_amd import engine
+    p = rand_params(N, H, seed=N + H + B, std=0.05)
+    r = np.random.RandomState(3)
+    y0 = torch.from_numpy(r.rand(B, 1, N).astype(np.float32)).to(dev)
+    t = torch.from_numpy(np.stack([np.array([0.0, 0.3 + 0.01 * b]) for b in range(B)]).astype(np.float32)).to(dev)
+    G = torch.from_numpy((r.randn(2, B, 1, N) / (B * N)).astype(np.float32)).to(dev)
+
+    def make():
+        net = make_net(pa, dev, p)
+        opt = torch.optim.SGD(net.parameters(), lr=0.05)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            y = y0.detach().requires_grad_(True)
+            sol = pa.odeint_adjoint(net, y, t, method=method)
+            torch.autograd.backward(sol, G)
+            opt.step()
+        return net, step
+
+    net_e, step_e = make()
+    for q in net_e.parameters():
+        q.grad = torch.zeros_like(q)
+    for _ in range(2 + 4):               # the graph's two warm-up runs (they update the parameters too) + four replays
+        step_e()
+    torch.cuda.synchronize()
+    net_g, step_g = make()
+    for q in net_g.parameters():
+        q.grad = torch.zeros_like(q)
+    gs = pa.GraphedStep(step_g, warmup=2)          # (the recording itself executes nothing)
+    assert engine.status_mode() == "immediate" and len(gs.status_blocks) >= 1
+    for _ in range(4):
+        gs()
+    gs.check_status()
+    torch.cuda.synchronize()
+    for a, b in zip(net_g.parameters(), net_e.parameters()):
+        assert torch.equal(a, b)
+    # an eager call after the replays sees the parameters the graph left (the layout cache was dropped)
+    sol_e = pa.odeint(net_e, y0, t, method=method).detach()
+    sol_g = pa.odeint(net_g, y0, t, method=method).detach()
+    assert torch.equal(sol_e, sol_g)
+    if method == "dopri5":
+        # failure inside a replay: NaN initial states stop every trajectory with a status, read on request
+        y0.fill_(float("nan"))
+        gs()
+        with pytest.raises((AssertionError, RuntimeError)):
+            gs.check_status()
+        y0.copy_(torch.from_numpy(r.rand(B, 1, N).astype(np.float32)))
+        engine.forget_workspaces()
+
+
 def test_zz_median_gradient_error_of_the_suite_meets_the_north_star_bar():
     """Runs last (file order): the MEDIAN engine-vs-reference error of every multi-step dopri5 gradient comparison this
     session made (oracle with the parameter block in the norm, goldens captured from torchdiffeq) is within the
