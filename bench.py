@@ -212,6 +212,25 @@ def full_training_step_ms(wl, net, y0, t, device, K=10000, reps=5):
         phoenix_amd.training_step(net, h, opt, wl["method"], y0.shape[0], False, False, X, prior_grad, 0.99)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
+    # ... and back to back, as a training loop issues them (deferred status: no host round trip inside a step); the figure
+    # above is the latency of ONE synchronised step, host time included
+    from phoenix_amd import engine
+    prev = engine.status_mode()
+    engine.set_status_mode("deferred")
+    try:
+        n = 4 * reps
+        for _ in range(2):
+            phoenix_amd.training_step(net, h, opt, wl["method"], y0.shape[0], False, False, X, prior_grad, 0.99)
+        engine.check_pending_status(wait=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            phoenix_amd.training_step(net, h, opt, wl["method"], y0.shape[0], False, False, X, prior_grad, 0.99)
+        engine.check_pending_status(wait=True)
+        torch.cuda.synchronize()
+        full_training_step_ms.back_to_back = (time.perf_counter() - t0) / n * 1e3
+    finally:
+        engine.set_status_mode(prev)
     return float(np.median(times[2:]))
 
 
@@ -598,6 +617,7 @@ def main(args):
                 K = 10000
                 ts_ms = full_training_step_ms(wl, net, y0, t, device, K=K)
                 out["training_step_ms"] = ts_ms
+                out["training_step_back_to_back_ms"] = getattr(full_training_step_ms, "back_to_back", None)
                 # algorithmic flops of the whole step: the two solves + the prior branch (forward 8KNH, backward with
                 # parameter gradients 16KNH); bytes: the solves' + 4P + 8KN (forward) + 8P + 12KN (backward)
                 ts_flop = flop_fwd + flop_adj + 24.0 * K * N * H
