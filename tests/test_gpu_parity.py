@@ -1126,11 +1126,12 @@ def test_wide_hidden_layer_paths(pa, dev, oracle):
             assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, N, H)
 
 
-@pytest.mark.parametrize("N,H,B", [(322, 120, 37), (500, 200, 20), (250, 120, 70), (777, 120, 12)])
+@pytest.mark.parametrize("N,H,B", [(322, 120, 37), (500, 200, 20), (250, 120, 70), (777, 120, 12), (400, 64, 10)])
 def test_half_block_gene_tiles_and_helper_waves_vs_oracle(pa, dev, oracle, monkeypatch, N, H, B):
     """Chunked third-generation kernels, HALF-BLOCK gene tiles (two workgroups per 32-gene block):
     three tiles and a last block whose second half is padding only (322 genes), two tiles with one helper wave each
-    (B = 20), two batch groups with at most 16 members (250 genes), one tile with three helper waves (B = 12) -- each
+    (B = 20), two batch groups with at most 16 members (250 genes), one tile with three helper waves (B = 12; with two
+    chunks, B = 10: more helpers than chunks) -- each
     against the oracle, and against whole-block tiles (PHX_V3C_HB=0: same steps, other summation order)."""
     import ctypes as C
     from phoenix_amd import _lib
