@@ -54,8 +54,24 @@ bool plan_adj3c(int N, int H, int B, int T, int control, int method, D1 *out, in
     for (int NW = 4; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 8; TPW <<= 1) {
             if (ftpw > 0 && TPW != ftpw) continue;
-            const int slots = NW * TPW, TG = (ntt + slots - 1) / slots;
-            const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
+            const int slots = NW * TPW;
+            int TG = (ntt + slots - 1) / slots;
+            int ntg = TG == 1 ? std::min(slots, ntt) : slots;
+            // More batch groups of FEWER trajectory tiles where the chip has room for them (one tile per wave plans, twice
+            // the gene blocks -- half-block tiles -- still resident): the groups' exchanges carry fewer rows and a tile gets
+            // helper waves (measured, round 5: -8 ... -32 % of a launch; 23 yeast pairs as two groups of one tile: neutral).
+            // PHX_V3C_NTG forces the tiles per group (4: the plan before this rule).
+            const int fntg = env_int("PHX_V3C_NTG", 0);
+            if (fntg > 0 && fntg <= slots) { ntg = std::min(fntg, ntt); TG = (ntt + ntg - 1) / ntg; }
+            else if (fntg == 0 && TPW == 1 && control != PHX_CTRL_SHARED) {
+                // (one-tile groups may take three quarters of the chip -- 23 yeast pairs as two groups on 252 workgroups
+                // measured +3 % --, two-tile groups all of it)
+                for (int c = 1; c < ntg; c <<= 1) {
+                    const int tgc = (ntt + c - 1) / c;
+                    if ((long long)tgc * nblk * 2 * 4 <= (long long)cus * (c == 1 ? 3 : 4)) { ntg = c; TG = tgc; break; }
+                }
+            }
+            const int Bt = 16 * ntg;
             const bool helpers = ntg < slots;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
             const size_t cb = ctl3c_bytes(Bt, ntg);

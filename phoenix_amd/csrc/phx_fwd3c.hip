@@ -52,8 +52,24 @@ bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, in
     for (int NW = 4; NW >= 1; NW >>= 1)
         for (int TPW = 1; TPW <= 8; TPW <<= 1) {
             if (ftpw > 0 && TPW != ftpw) continue;
-            const int slots = NW * TPW, TG = (ntt + slots - 1) / slots;
-            const int ntg = TG == 1 ? std::min(slots, ntt) : slots, Bt = 16 * ntg;
+            const int slots = NW * TPW;
+            int TG = (ntt + slots - 1) / slots;
+            int ntg = TG == 1 ? std::min(slots, ntt) : slots;
+            // More batch groups of FEWER trajectory tiles where the chip has room for them (one tile per wave plans, twice
+            // the gene blocks -- half-block tiles -- still resident): the groups' exchanges carry fewer rows and a tile gets
+            // helper waves (measured, round 5: -8 ... -32 % of a launch; 23 yeast pairs as two groups of one tile: neutral).
+            // PHX_V3C_NTG forces the tiles per group (4: the plan before this rule).
+            const int fntg = env_int("PHX_V3C_NTG", 0);
+            if (fntg > 0 && fntg <= slots) { ntg = std::min(fntg, ntt); TG = (ntt + ntg - 1) / ntg; }
+            else if (fntg == 0 && TPW == 1 && control != PHX_CTRL_SHARED) {
+                // (one-tile groups may take three quarters of the chip, two-tile groups half of it: beyond, the forward
+                // launch measured +8 ... +18 % -- 252 half-block workgroups at two tiles per group -- where the backward gains)
+                for (int c = 1; c < ntg; c <<= 1) {
+                    const int tgc = (ntt + c - 1) / c;
+                    if ((long long)tgc * nblk * 2 * 4 <= (long long)cus * (c == 1 ? 3 : 2)) { ntg = c; TG = tgc; break; }
+                }
+            }
+            const int Bt = 16 * ntg;
             const bool helpers = ntg < slots;
             if (control == PHX_CTRL_SHARED && TG != 1) continue;
             const size_t cb = ctlf3c_bytes(Bt, ntg);
@@ -73,9 +89,10 @@ bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, in
                     best.Bcall = 0; best.cntN = (long long)B * N; best.res = res ? 1 : 0;
                     const int nslot = TPW * NB;
                     // measured (round 5, H = 120 / 200, 8..220 gene blocks, 16..128 trajectories): -9..-33 % of a launch while
-                    // the workgroups cover at most half the chip, +5..+24 % beyond (tools/v3c_check.py hbgrid)
+                    // the groups' rows times their workgroups stay small (four-tile groups on at most half the chip, one-tile
+                    // groups on all of it) and a group has at most 160 members; +5..+24 % beyond (tools/v3c_check.py hbgrid)
                     const bool hb_fits = nslot == 1 && res && (long long)TG * G * 2 <= cus && cb + HSF_BYTES + 16 + blkbytes * HC <= LDS_BUDGET;
-                    best.hb = (hb_fits && fhb != 0 && (fhb == 1 || (long long)TG * G * 4 <= cus)) ? 1 : 0;
+                    best.hb = (hb_fits && fhb != 0 && (fhb == 1 || ((long long)TG * G * ntg <= cus && 2 * nblk <= 160))) ? 1 : 0;
                     best_nbt = nslot <= 1 ? 1 : 8;   // (unused slots of the eight-slot form cost a scalar branch each)
                 }
             }

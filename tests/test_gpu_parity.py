@@ -1144,14 +1144,20 @@ def test_half_block_gene_tiles_and_helper_waves_vs_oracle(pa, dev, oracle, monke
     ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
     adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
     out = {}
-    for hb in ("1", "0"):
-        monkeypatch.setenv("PHX_V3C_HB", hb)
+    # "1": the default plan (where the chip has room: batch groups of one or two tiles, their helper waves);
+    # "4": half-block tiles in the four-tile groups of the plan before that rule; "0": whole-block tiles
+    for hb in ("1", "4", "0"):
+        monkeypatch.setenv("PHX_V3C_HB", "0" if hb == "0" else "1")
+        if hb == "1":
+            monkeypatch.delenv("PHX_V3C_NTG", raising=False)
+        else:
+            monkeypatch.setenv("PHX_V3C_NTG", "4")
         lib = _lib.load()
         plan = (C.c_int * 6)()
         off, nwg = C.c_size_t(0), C.c_int(0)
         for op in (_lib.OP_ODEINT, _lib.OP_ADJOINT):
             assert lib.phx_debug_profile_region(op, N, H, B, 2, _lib.CTRL_PER_TRAJECTORY, C.byref(off), C.byref(nwg), plan) == 0
-            assert (plan[5] % 10) // 2 == int(hb), (op, list(plan))   # the half-block form runs where the test says it does
+            assert (plan[5] % 10) // 2 == (0 if hb == "0" else 1), (op, list(plan))   # the half-block form runs where the test says it does
         for q in net.parameters():
             q.grad = None
         y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
@@ -1164,9 +1170,10 @@ def test_half_block_gene_tiles_and_helper_waves_vs_oracle(pa, dev, oracle, monke
         for k in KEYS:
             assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, hb)
         out[hb] = (got, gg)
-    assert relerr(out["1"][0], out["0"][0]) < TOL_DOPRI
-    for k in KEYS:
-        assert relerr(out["1"][1][k], out["0"][1][k]) < TOL_DOPRI_GRAD, k
+    for v in ("1", "4"):
+        assert relerr(out[v][0], out["0"][0]) < TOL_DOPRI
+        for k in KEYS:
+            assert relerr(out[v][1][k], out["0"][1][k]) < TOL_DOPRI_GRAD, (k, v)
 
 
 @pytest.mark.parametrize("N,H,K", [(350, 40, 1500), (1537, 24, 1100), (600, 120, 1100), (11165, 40, 2100), (500, 200, 1100)])

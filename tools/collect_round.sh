@@ -22,5 +22,6 @@ PHX_PROF=1 timeout 200 python tools/prof_segments.py bcell adj 128 > profiles/${
 PHX_PROF=1 timeout 200 python tools/prof_segments.py bcell fwd > profiles/${TAG}_bcell_segments_fwd3c.txt 2>&1
 timeout 400 python tools/v3c_check.py time > profiles/${TAG}_v3c_old_vs_new_time.txt 2>&1
 timeout 600 python tools/v3c_check.py hbgrid > profiles/${TAG}_v3c_half_block_grid.txt 2>&1
+timeout 600 python tools/v3c_check.py ntggrid > profiles/${TAG}_v3c_tiles_per_group_grid.txt 2>&1
 mkdir -p $OUT/profiles; cp profiles/${TAG}_* $OUT/profiles/
 ls -la $OUT/profiles | head -40

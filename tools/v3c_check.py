@@ -17,7 +17,7 @@ from phoenix_amd import _lib, engine  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 dev = torch.device("cuda:0")
-ENVK = ("PHX_V3C", "PHX_V3C_HB", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
+ENVK = ("PHX_V3C", "PHX_V3C_HB", "PHX_V3C_NTG", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
 
 
 def relerr(a, b):
@@ -189,6 +189,17 @@ if __name__ == "__main__":
         timing("yeast N=2000 H=120 B=4", 2000, 120, 4, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
         timing("yeast N=2000 H=120 B=128", 2000, 120, 128, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
         timing("N=350 H=100 B=64", 350, 100, 64, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}])
+    if mode == "ntg":       # trajectory tiles per batch group (more groups of fewer tiles: more helper waves per tile)
+        for B in (23, 40, 64):
+            timing("yeast N=2000 H=120 B=%d" % B, 2000, 120, B, [0.0, 5.0], 0.05, 0.95,
+                   [{}, {"PHX_V3C_NTG": "1"}, {"PHX_V3C_NTG": "1", "PHX_V3C_HB": "1"}, {"PHX_V3C_NTG": "2"}], yrange=(-0.3, 0.9))
+        timing("N=600 H=120 B=64", 600, 120, 64, [0.0, 2.0], 0.05, 0.95, [{}, {"PHX_V3C_NTG": "1"}, {"PHX_V3C_NTG": "2"}])
+        timing("N=1000 H=200 B=32", 1000, 200, 32, [0.0, 2.0], 0.05, 0.95, [{}, {"PHX_V3C_NTG": "1"}])
+    if mode == "ntggrid":   # the tiles-per-group rule against the plan before it (PHX_V3C_NTG=4)
+        for H in (120, 200):
+            for N in (250, 350, 600, 1000, 2000, 3500) if H == 120 else (350, 1000, 2000):
+                for B in (16, 23, 32, 40, 48, 64, 100, 128):
+                    timing("N=%d H=%d B=%d" % (N, H, B), N, H, B, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_NTG": "4"}, {}], reps=3)
     if mode == "hbgrid":    # where half-block tiles pay: gene blocks x trajectory tiles
         for N in (250, 350, 600, 800, 1000, 2000, 3500):
             for B in (16, 32, 48, 64, 128):
