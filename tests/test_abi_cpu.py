@@ -166,3 +166,42 @@ def test_odeint_on_a_differentiable_odenet_is_routed_to_the_adjoint(monkeypatch)
     assert phoenix_amd.odeint(net, y0, t, method="rk4") == "routed" and seen["_via_odeint"] and seen["method"] == "rk4"
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path|must live on the GPU"):
         phoenix_amd.odeint(net, y0, t)          # not routed: the plain forward solve (which has no CPU path)
+
+
+def test_plan_switches_are_read_from_the_live_environment(monkeypatch):
+    """engine._plan_env (the fast read of the PHX_* plan switches that keys workspaces and plans) follows os.environ as
+    the tests and tools change it, and equals the plain os.environ.get reading"""
+    import os
+    from phoenix_amd import engine
+    monkeypatch.delenv("PHX_V3C_HB", raising=False)
+    monkeypatch.delenv("PHX_ADJ", raising=False)
+    base = engine._plan_env()
+    assert len(base) == len(engine._PLAN_ENV)
+    monkeypatch.setenv("PHX_V3C_HB", "0")
+    monkeypatch.setenv("PHX_ADJ", "v2")
+    now = engine._plan_env()
+    assert now != base
+    plain = tuple(os.environ.get(k) for k in engine._PLAN_ENV)
+    assert tuple(None if v is None else os.fsdecode(v) if isinstance(v, bytes) else v for v in now) == plain
+    monkeypatch.delenv("PHX_V3C_HB")
+    monkeypatch.delenv("PHX_ADJ")
+    assert engine._plan_env() == base
+
+
+def test_status_modes():
+    """"captured" keeps device status blocks for check_captured_status and never blocks; host blocks are checked at once"""
+    import torch
+    from phoenix_amd import engine
+    assert engine.status_mode() == "immediate"
+    engine.set_status_mode("captured")
+    try:
+        engine.check_pending_status(wait=True)                     # nothing to wait for, no event calls
+        engine.raise_for_status(torch.zeros(4, dtype=torch.int32))  # a host block: read right away
+        with pytest.raises(AssertionError):
+            engine.raise_for_status(torch.tensor([0, 1, 0], dtype=torch.int32))
+        assert engine.captured_status == []
+    finally:
+        engine.set_status_mode("immediate")
+    with pytest.raises(AssertionError):
+        engine.set_status_mode("later")
+
