@@ -95,6 +95,15 @@ bool plan_adj3c(int N, int H, int B, int T, int control, int method, D1 *out, in
                     const bool hb_fits = nslot == 1 && res && (long long)TG * G * 2 <= cus && cb + HSA_BYTES + 16 + blkbytes * HC <= LDS_BUDGET;
                     best.hb = (hb_fits && fhb != 0) ? 1 : 0;
                     best_nbt = nslot <= 1 ? 1 : 4;
+                    // block split: a tile's gene blocks on the workgroup's spare waves (plan_fwd3c)
+                    best.split = 1;
+                    if (!best.hb && TPW == 1 && NB > 1 && ntg * NB <= NW && env_int("PHX_V3C_SPLIT", 1) != 0) {
+                        const int parts = std::min(NW / ntg, NB);
+                        if (hsa_offset(Bt, ntg) + spa_bytes(ntg, parts) + blkbytes * NB * (res ? HC : 1) <= LDS_BUDGET) {
+                            best.split = parts;
+                            best_nbt = 1;
+                        }
+                    }
                 }
             }
         }
@@ -146,7 +155,9 @@ Layout3C make_layout3c(const D1 &d, bool grads)
 
 size_t lds_bytes_adj3c(const D1 &d)
 {
-    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + (d.hb ? hsa_offset(d.Bt, d.ntg) + HSA_BYTES : ctl3c_bytes(d.Bt, d.ntg));
+    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) +
+           (d.hb ? hsa_offset(d.Bt, d.ntg) + HSA_BYTES
+                 : (d.split > 1 ? hsa_offset(d.Bt, d.ntg) + spa_bytes(d.ntg, d.split) : ctl3c_bytes(d.Bt, d.ntg)));
 }
 
 }  // namespace
@@ -172,7 +183,7 @@ int adj3c_profile_region(int N, int H, int B, int T, int control, size_t *offset
     if (!plan_adj3c(N, H, B, T, control, PHX_DOPRI5, &d1, nullptr)) return PHX_ERR_BAD_ARG;
     *offset = make_layout3c(d1, true).prof;
     *n_workgroups = d1.TG * d1.G;
-    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb; }
+    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb + (d1.split > 1 ? 4 : 0); }
     return PHX_OK;
 }
 

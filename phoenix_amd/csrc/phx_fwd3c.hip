@@ -94,6 +94,15 @@ bool plan_fwd3c(int N, int H, int B, int T, int control, int method, D1 *out, in
                     const bool hb_fits = nslot == 1 && res && (long long)TG * G * 2 <= cus && cb + HSF_BYTES + 16 + blkbytes * HC <= LDS_BUDGET;
                     best.hb = (hb_fits && fhb != 0 && (fhb == 1 || ((long long)TG * G * ntg <= cus && 2 * nblk <= 160))) ? 1 : 0;
                     best_nbt = nslot <= 1 ? 1 : 8;   // (unused slots of the eight-slot form cost a scalar branch each)
+                    // block split: a tile's gene blocks on the workgroup's spare waves (small batches of multi-block tiles)
+                    best.split = 1;
+                    if (!best.hb && TPW == 1 && NB > 1 && ntg * NB <= NW && env_int("PHX_V3C_SPLIT", 1) != 0) {
+                        const int parts = std::min(NW / ntg, NB);
+                        if (hsf_offset(Bt, ntg) + spf_bytes(ntg, parts) + blkbytes * NB * (res ? HC : 1) <= LDS_BUDGET) {
+                            best.split = parts;
+                            best_nbt = 1;
+                        }
+                    }
                 }
             }
         }
@@ -139,7 +148,9 @@ LayoutF3C make_layout_f3c(const D1 &d)
 
 size_t lds_bytes_fwd3c(const D1 &d)
 {
-    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) + (d.hb ? hsf_offset(d.Bt, d.ntg) + HSF_BYTES : ctlf3c_bytes(d.Bt, d.ntg));
+    return (size_t)blk_floats_ch(d.HT, d.Hc) * 4 * d.NB * (d.res ? d.HC : 1) +
+           (d.hb ? hsf_offset(d.Bt, d.ntg) + HSF_BYTES
+                 : (d.split > 1 ? hsf_offset(d.Bt, d.ntg) + spf_bytes(d.ntg, d.split) : ctlf3c_bytes(d.Bt, d.ntg)));
 }
 
 }  // namespace
@@ -165,7 +176,7 @@ int fwd3c_profile_region(int N, int H, int B, int T, int control, size_t *offset
     if (!plan_fwd3c(N, H, B, T, control, PHX_DOPRI5, &d1, nullptr)) return PHX_ERR_BAD_ARG;
     *offset = make_layout_f3c(d1).prof;
     *n_workgroups = d1.TG * d1.G;
-    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb; }
+    if (plan6) { plan6[0] = d1.NW; plan6[1] = d1.TPW; plan6[2] = d1.NB; plan6[3] = d1.G; plan6[4] = d1.TG; plan6[5] = d1.HC * 10 + d1.res + 2 * d1.hb + (d1.split > 1 ? 4 : 0); }
     return PHX_OK;
 }
 

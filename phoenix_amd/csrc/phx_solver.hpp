@@ -45,6 +45,7 @@ struct D1 {
     int res;   // chunked third-generation kernels (k1_solve_fwd3c / adj3c): 1 = the images of ALL hidden chunks of the
                // workgroup's gene blocks stay LDS resident, 0 = one chunk slot, re-staged as the sweeps walk the chunks
     int hb;    // chunked kernels: 1 = HALF-BLOCK gene tiles (G = 2 * nblk workgroups per batch group, 16 genes each)
+    int split; // chunked kernels: > 1 = the waves of a trajectory tile take its gene blocks (block `wave / ntg`), partial rows added in LDS
 };
 
 struct W1 {

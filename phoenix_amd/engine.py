@@ -43,7 +43,7 @@ def _stream_ptr():
 _ws_bytes = {}
 _PLAN_ENV = ("PHX_ENGINE", "PHX_ADJ", "PHX_ADJ2_NP", "PHX_V1_MAXNW", "PHX_PGRAD", "PHX_EVAL_NBC", "PHX_PGRAD_KS", "PHX_FWD", "PHX_V3_NB",
              "PHX_V3_HALF", "PHX_BATCH_MIN_ROWS", "PHX_PGRAD_WGS", "PHX_PGRAD_G4", "PHX_BATCH_CHUNK_MIN", "PHX_V3C", "PHX_V3C_NB",
-             "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_V3C_HB", "PHX_V3C_NTG")
+             "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_V3C_HB", "PHX_V3C_NTG", "PHX_V3C_SPLIT")
 
 
 _PLAN_ENV_B = tuple(os.fsencode(k) for k in _PLAN_ENV)

@@ -1619,6 +1619,51 @@ def test_other_stream_and_mixed_time_directions(pa, dev, oracle):
 
 
 
+@pytest.mark.parametrize("N,H,B,T,env", [(1500, 200, 10, 2, {"PHX_V3C_NB": "4", "PHX_V3C_RES": "0"}),
+                                         (777, 120, 20, 3, {"PHX_V3C_NB": "2"}),
+                                         (1511, 200, 7, 2, {"PHX_V3C_NB": "2", "PHX_V3C_RES": "0"})])
+def test_block_split_of_the_chunked_kernels_vs_oracle(pa, dev, oracle, monkeypatch, N, H, B, T, env):
+    """Chunked third-generation kernels on multi-block gene tiles with few trajectory tiles (the B-cell shape at the reference's
+    batch of 2 is the natural case; smaller problems get there with a forced tile size): the waves of a tile take its gene
+    blocks, partial rows and norm partials are added in LDS (four parts on re-staged chunks, two parts x two tiles on resident
+    ones, a last gene tile with fewer blocks than parts) -- against the oracle, and against the unsplit form."""
+    import ctypes as C
+    from phoenix_amd import _lib
+    p = rand_params(N, H, seed=5 * N + H, std=0.03)
+    net, onet = make_net(pa, dev, p), onet_of(oracle, p)
+    r = np.random.RandomState(4)
+    y0 = r.rand(B, N).astype(np.float32)
+    t = np.stack([np.linspace(0.0, 0.4 + 0.01 * (b % 5), T) for b in range(B)]).astype(np.float32)
+    G = r.randn(B, T, N).astype(np.float32)
+    ref = oracle.odeint_per_sample(onet, y0, t, method="dopri5")
+    adj_ref, gr_ref = oracle.adjoint_backward_per_sample(onet, t, ref, G, method="dopri5", theta_in_norm=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("PHX_V3C_SPLIT", split)
+        plan = (C.c_int * 6)()
+        off, nwg = C.c_size_t(0), C.c_int(0)
+        for op in (_lib.OP_ODEINT, _lib.OP_ADJOINT):
+            assert _lib.load().phx_debug_profile_region(op, N, H, B, T, _lib.CTRL_PER_TRAJECTORY, C.byref(off), C.byref(nwg), plan) == 0
+            assert (plan[5] % 10) // 4 == int(split), (op, list(plan))
+        for q in net.parameters():
+            q.grad = None
+        y0t = torch.from_numpy(y0).to(dev).reshape(B, 1, N).requires_grad_(True)
+        sol = pa.odeint_adjoint(net, y0t, torch.from_numpy(t).to(dev))
+        got = sol.detach().cpu().numpy().reshape(T, B, N).transpose(1, 0, 2)
+        assert relerr(got, ref) < TOL_DOPRI, split
+        (sol * torch.from_numpy(G.transpose(1, 0, 2).reshape(T, B, 1, N).copy()).to(dev)).sum().backward()
+        assert grad_err(y0t.grad.cpu().numpy().reshape(B, N), adj_ref) < TOL_DOPRI_GRAD, split
+        gg = grads_of(net)
+        for k in KEYS:
+            assert grad_err(gg[k], gr_ref[k]) < TOL_DOPRI_GRAD, (k, split)
+        out[split] = (got, gg)
+    assert relerr(out["1"][0], out["0"][0]) < TOL_DOPRI
+    for k in KEYS:
+        assert relerr(out["1"][1][k], out["0"][1][k]) < TOL_DOPRI_GRAD, k
+
+
 def test_small_problem_with_training_scale_cotangents_vs_oracle_with_and_without_theta(pa, dev, oracle):
     """The regime DESIGN.md section 5 once blamed on the theta block of the adjoint norm (adjoint.py:72-78; the engine's
     controllers see [t, y, a] only): 700 genes, 6 trajectories, cotangents of training scale 1/(B N), where atol dominates

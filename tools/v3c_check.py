@@ -17,7 +17,7 @@ from phoenix_amd import _lib, engine  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 dev = torch.device("cuda:0")
-ENVK = ("PHX_V3C", "PHX_V3C_HB", "PHX_V3C_NTG", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
+ENVK = ("PHX_V3C", "PHX_V3C_HB", "PHX_V3C_NTG", "PHX_V3C_SPLIT", "PHX_V3C_NB", "PHX_V3C_TPW", "PHX_V3C_RES", "PHX_V3C_SLOTS", "PHX_ADJ", "PHX_FWD")
 
 
 def relerr(a, b):
@@ -191,6 +191,15 @@ if __name__ == "__main__":
         timing("yeast N=2000 H=120 B=4", 2000, 120, 4, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
         timing("yeast N=2000 H=120 B=128", 2000, 120, 128, [0.0, 5.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}], yrange=(-0.3, 0.9))
         timing("N=350 H=100 B=64", 350, 100, 64, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_HB": "0"}, {}])
+    if mode == "split":     # block split of small batches on multi-block gene tiles
+        case("H=200 restaged NB=4, one tile, split 4", 1500, 200, 10, grids(10, 0.0, 0.3, spread=0.002), 0.02,
+             env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "4"})
+        case("H=120 resident NB=2, two tiles, split 2", 777, 120, 20, grids(20, 0.0, 0.5, T=3), 0.03, env={"PHX_V3C_NB": "2"})
+        case("H=200 restaged NB=2, ragged last tile", 1511, 200, 7, grids(7, 0.4, 0.0), 0.02, env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "2"})
+        case("same, split off", 1511, 200, 7, grids(7, 0.4, 0.0), 0.02, env={"PHX_V3C_RES": "0", "PHX_V3C_NB": "2", "PHX_V3C_SPLIT": "0"})
+        case("B-cell shape, 2 trajectories", 14691, 200, 2, grids(2, 0.0, 1.0), 0.003, with_oracle=False, sparse=0.95)
+        timing("bcell N=14691 H=200 B=2", 14691, 200, 2, [0.0, 1.0], 0.05, 0.95, [{"PHX_V3C_SPLIT": "0"}, {}, {"PHX_V3C_NB": "4"}], reps=5)
+        timing("N=9000 H=120 B=16", 9000, 120, 16, [0.0, 2.0], 0.05, 0.95, [{"PHX_V3C_SPLIT": "0"}, {}], reps=5)
     if mode == "fuzz":      # random shapes: the default plans against whole-block tiles in four-tile groups and the older kernels
         rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
         worst = 0.0
