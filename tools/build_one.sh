@@ -9,4 +9,6 @@ done
 wait
 for u in "$@"; do grep -i "error" /tmp/build_$u.log | head -5; f=$(ls _obj/$u-hip-amdgcn-amd-amdhsa-gfx950.s 2>/dev/null); [ -n "$f" ] && mv $f _obj/$u.s; rm -f _obj/$u-hip-* _obj/$u-host-* ; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libphoenix_hip.so _obj/phx_adj2.o _obj/phx_adj3.o _obj/phx_adj3c.o _obj/phx_engine.o _obj/phx_fwd3.o _obj/phx_fwd3c.o _obj/phx_v1.o
-touch _obj/*.o ../libphoenix_hip.so
+# (only the library is marked fresh: objects of other units that a header edit made stale stay stale, so that
+#  `python -m phoenix_amd.build` rebuilds them -- a library linked here may mix objects of two header versions)
+touch ../libphoenix_hip.so
